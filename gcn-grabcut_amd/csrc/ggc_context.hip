@@ -1,0 +1,86 @@
+// ggc_context.hip — context, error reporting, scratch arena.
+#include "ggc_internal.h"
+#include <cstdarg>
+#include <mutex>
+
+static std::string g_create_err;
+
+namespace ggc {
+
+int set_err(ggc_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_err = buf;
+    return code;
+}
+
+void* scratch(ggc_ctx* ctx, int slot, size_t bytes) {
+    Buf& b = ctx->slots[slot];
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return b.p;
+    if (b.p) {
+        // hipFree synchronises the device, so no kernel still reads the old buffer.
+        if (hipFree(b.p) != hipSuccess) { set_err(ctx, GGC_E_DEVICE, "hipFree failed"); return nullptr; }
+        b.p = nullptr; b.bytes = 0;
+    }
+    size_t want = bytes + bytes / 4;           // headroom so ragged batches rarely regrow
+    want = (want + 255) & ~size_t(255);
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        set_err(ctx, GGC_E_OOM, "hipMalloc(%zu) failed for scratch slot %d", want, slot);
+        return nullptr;
+    }
+    b.p = p; b.bytes = want;
+    return p;
+}
+
+} // namespace ggc
+
+extern "C" {
+
+int ggc_version(void) { return GGC_VERSION; }
+
+int ggc_ctx_create(int device_id, ggc_ctx** out) {
+    if (!out) return ggc::set_err(nullptr, GGC_E_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return ggc::set_err(nullptr, GGC_E_DEVICE, "no HIP device available (%s)",
+                            e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return ggc::set_err(nullptr, GGC_E_INVALID_ARG, "device_id %d out of range [0,%d)", device_id, n);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return ggc::set_err(nullptr, GGC_E_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return ggc::set_err(nullptr, GGC_E_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only",
+                            device_id, prop.gcnArchName);
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return ggc::set_err(nullptr, GGC_E_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+    ggc_ctx* c = new (std::nothrow) ggc_ctx();
+    if (!c) return ggc::set_err(nullptr, GGC_E_OOM, "host allocation failed");
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return GGC_OK;
+}
+
+int ggc_ctx_destroy(ggc_ctx* ctx) {
+    if (!ctx) return GGC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& b : ctx->slots) if (b.p) (void)hipFree(b.p);
+    for (auto& kv : ctx->model.dev) if (kv.second.p) (void)hipFree(kv.second.p);
+    delete ctx;
+    return GGC_OK;
+}
+
+const char* ggc_last_error(const ggc_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+} // extern "C"

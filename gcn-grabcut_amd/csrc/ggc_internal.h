@@ -1,0 +1,126 @@
+// ggc_internal.h — shared internals of libggc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/ggc.h"
+
+namespace ggc {
+
+constexpr int WAVE = 64;
+
+// Scratch slots: one growing device buffer per slot, owned by the context.
+enum Slot : int {
+    S_CSR_ROWPTR = 0, S_CSR_COL, S_CSR_EID, S_CSR_CURSOR, S_DIS, S_BATCH,
+    S_STATES, S_GATE, S_XW, S_AGG, S_SCORE, S_GVEC, S_HJK,
+    S_PRE_A, S_PRE_B, S_PRE_C, S_PRE_D,
+    S_SLIC_IMG, S_SLIC_TMP, S_SLIC_CENTERS, S_SLIC_DIST, S_SLIC_LABELS, S_SLIC_AUX,
+    S_SLIC_AUX2, S_SLIC_AUX3, S_SLIC_AUX4, S_SLIC_MINMAX,
+    S_G_STATS, S_G_FEAT, S_G_PAIRS, S_G_PAIRCNT, S_G_NL, S_G_EDGE_SRC, S_G_EDGE_DST,
+    S_G_EDGE_ATTR, S_G_PTR, S_G_PRIOR, S_G_AUX, S_G_AUX2, S_G_AUX3, S_G_X,
+    S_T_A, S_T_B, S_T_C,
+    S_GC_A, S_GC_B, S_GC_C, S_GC_D, S_GC_E, S_GC_F, S_GC_G, S_GC_H, S_GC_I, S_GC_J,
+    S_GC_K, S_GC_L, S_GC_M, S_GC_N,
+    S_CC_A, S_CC_B, S_CC_C,
+    S_MISC_A, S_MISC_B,
+    S_COUNT
+};
+
+struct Buf {
+    void*  p = nullptr;
+    size_t bytes = 0;
+};
+
+// ResGCNNet parameters (reference model.py:449-499): host copies by state_dict
+// key, device copies (raw + packed layouts) built lazily before a forward.
+struct ResgcnWeights {
+    int D = 0, n_layers = 0, Q = 0, C = 0;
+    std::map<std::string, std::vector<float>> host;
+    std::map<std::string, Buf> dev;
+    bool dev_ok = false;
+};
+
+// Result of ggc_graph_count kept until ggc_graph_fill.
+struct GraphState {
+    int B = 0, H = 0, W = 0;
+    int64_t n_total = 0, e_total = 0;
+    std::vector<int64_t> node_ptr, edge_ptr;
+    bool valid = false;
+};
+
+} // namespace ggc
+
+struct ggc_ctx {
+    int device = 0;
+    std::string err;
+    ggc::Buf slots[ggc::S_COUNT];
+    ggc::ResgcnWeights model;
+    ggc::GraphState graph;
+    int n_cu = 256;
+};
+
+namespace ggc {
+
+int set_err(ggc_ctx* ctx, int code, const char* fmt, ...);
+// Returns nullptr (and sets error) on failure. Content is NOT preserved on growth.
+void* scratch(ggc_ctx* ctx, int slot, size_t bytes);
+
+#define GGC_HIP(ctx, expr)                                                          \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess)                                                       \
+            return ggc::set_err((ctx), GGC_E_DEVICE, "%s failed: %s (%s:%d)", #expr, \
+                                hipGetErrorString(_e), __FILE__, __LINE__);          \
+    } while (0)
+
+#define GGC_LAUNCH_CHECK(ctx)                                                        \
+    do {                                                                            \
+        hipError_t _e = hipGetLastError();                                          \
+        if (_e != hipSuccess)                                                       \
+            return ggc::set_err((ctx), GGC_E_DEVICE, "kernel launch failed: %s (%s:%d)", \
+                                hipGetErrorString(_e), __FILE__, __LINE__);          \
+    } while (0)
+
+#define GGC_REQUIRE(ctx, cond, code, ...)                      \
+    do {                                                       \
+        if (!(cond)) return ggc::set_err((ctx), (code), __VA_ARGS__); \
+    } while (0)
+
+template <typename T>
+inline T* scratch_t(ggc_ctx* ctx, int slot, size_t count) {
+    return reinterpret_cast<T*>(scratch(ctx, slot, count * sizeof(T)));
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// XCD-aware block remap: blocks b and b+8 share an XCD (observed round-robin
+// placement; speed only).  Maps the hardware block id to a logical id so that
+// each XCD walks one contiguous chunk of logical blocks.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7;       // chunks: first r XCDs get q+1 blocks
+    const int xcd = b & 7, slot = b >> 3;
+    const int base = xcd * q + (xcd < r ? xcd : r);
+    return base + slot;
+}
+
+} // namespace ggc

@@ -1,0 +1,920 @@
+// ggc_resgcn.hip — ResGCNNet forward (reference model.py:421-546, eval mode) as
+// hand-written gfx950 kernels.
+//
+// Kernel map:
+//   k_input        M1  BatchNorm-eval -> Linear 19->D -> LayerNorm -> GELU -> prior booster
+//   k_edge_gate    M2  EdgeContext: edge MLP, mean over incoming edges, LN, Linear, sigmoid
+//   k_gemm<.,0>    M3  LayerNorm(h) @ W^T on f32 MFMA (v_mfma_f32_32x32x2_f32)
+//   k_aggregate<.,0>  M3  GCNConv scatter-gather over the destination CSR with the
+//                      fused epilogue h + gelu((agg + b) * gate)       <- graded kernel
+//   k_aggregate<.,1>  M4  SAGEConv mean aggregation
+//   k_gemm<.,1>    M4  lin_l(mean) + lin_r(h), LayerNorm, GELU (two MFMA phases)
+//   k_jk           M5  softmax(jk_logits)-weighted sum of the n+2 states + attention score
+//   k_graph_ctx    M6  per-graph softmax readout, compress/expand MLP
+//   k_gemm<.,2>    M7  (h_jk * g) -> LN -> Linear -> GELU -> head -> softmax
+//
+// Data layout in HBM: node-major row vectors, f32, D contiguous (512 B rows at
+// D=128).  Graphs of a batch are concatenated (PyG Batch semantics); node_ptr
+// gives the per-graph ranges.  The destination CSR (row_ptr, col, eid) is
+// built once per forward, stable in edge order, and reused by all 8 gathers.
+#include "ggc_internal.h"
+#include <cmath>
+
+namespace ggc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int IN_CH = 19, EDGE_CH = 5, N_PRIOR = 3, N_CLS = 3;
+
+// ------------------------------------------------------------------ CSR build
+
+__global__ void k_count_dst(int E, const int32_t* __restrict__ dst, int32_t* __restrict__ cnt) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x)
+        atomicAdd(&cnt[dst[e]], 1);
+}
+
+// Single-block exclusive scan of cnt[0..n) into out[0..n], out[n] = total.
+__global__ void __launch_bounds__(1024) k_exclusive_scan(int n, const int32_t* __restrict__ cnt,
+                                                         int32_t* __restrict__ out) {
+    __shared__ int32_t part[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int beg = tid * chunk;
+    const int end = min(beg + chunk, n);
+    int32_t s = 0;
+    for (int i = beg; i < end; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int32_t v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int32_t run = (tid == 0) ? 0 : part[tid - 1];
+    for (int i = beg; i < end; ++i) { int32_t c = cnt[i]; out[i] = run; run += c; }
+    if (tid == 1023) out[n] = part[1023];
+}
+
+__global__ void k_fill_eid(int E, const int32_t* __restrict__ dst, const int32_t* __restrict__ row_ptr,
+                           int32_t* __restrict__ cursor, int32_t* __restrict__ eid) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const int d = dst[e];
+        const int pos = row_ptr[d] + atomicAdd(&cursor[d], 1);
+        eid[pos] = e;
+    }
+}
+
+// One thread per row: restore edge order inside the row (stable CSR), emit col and dis.
+__global__ void k_sort_rows(int N, const int32_t* __restrict__ row_ptr, int32_t* __restrict__ eid,
+                            const int32_t* __restrict__ src, int32_t* __restrict__ col,
+                            float* __restrict__ dis) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < N; r += gridDim.x * blockDim.x) {
+        const int beg = row_ptr[r], end = row_ptr[r + 1];
+        for (int i = beg + 1; i < end; ++i) {
+            const int v = eid[i];
+            int j = i - 1;
+            while (j >= beg && eid[j] > v) { eid[j + 1] = eid[j]; --j; }
+            eid[j + 1] = v;
+        }
+        for (int i = beg; i < end; ++i) col[i] = src[eid[i]];
+        if (dis) dis[r] = 1.0f / sqrtf((float)(end - beg) + 1.0f);
+    }
+}
+
+__global__ void k_fill_batch(int G, int N, const int32_t* __restrict__ node_ptr, int32_t* __restrict__ batch) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        int lo = 0, hi = G; // find g with node_ptr[g] <= i < node_ptr[g+1]
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (node_ptr[mid] <= i) lo = mid; else hi = mid; }
+        batch[i] = lo;
+    }
+}
+
+static int build_csr(ggc_ctx* ctx, hipStream_t st, int N, int E, const int32_t* src, const int32_t* dst,
+                     int32_t* row_ptr, int32_t* col, int32_t* eid, int32_t* cursor, float* dis) {
+    GGC_HIP(ctx, hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)(N + 1), st));
+    if (E > 0) {
+        hipLaunchKernelGGL(k_count_dst, dim3(min(cdiv(E, 256), 4096)), dim3(256), 0, st, E, dst, cursor);
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, N, cursor, row_ptr);
+    GGC_LAUNCH_CHECK(ctx);
+    GGC_HIP(ctx, hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)(N + 1), st));
+    if (E > 0) {
+        hipLaunchKernelGGL(k_fill_eid, dim3(min(cdiv(E, 256), 4096)), dim3(256), 0, st, E, dst, row_ptr, cursor, eid);
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(k_sort_rows, dim3(min(cdiv(N, 256), 4096)), dim3(256), 0, st, N, row_ptr, eid, src, col, dis);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
+
+// --------------------------------------------------------------- M1: input stage
+// One wave per node; lane owns columns lane + 64 j.
+struct InputW {
+    const float *bn_w, *bn_b, *bn_rm, *bn_rv;
+    const float *w_inT /*[19][D]*/, *b_in, *ln_w, *ln_b;
+    const float *pb_w0 /*[Q,3]*/, *pb_b0, *pb_w2T /*[Q][D]*/, *pb_b2;
+};
+
+template <int D>
+__global__ void __launch_bounds__(256) k_input(int N, const float* __restrict__ x, InputW w, int Q,
+                                               float* __restrict__ h) {
+    constexpr int NC = (D + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int node = wave; node < N; node += n_waves) {
+        const float* xi = x + (size_t)node * IN_CH;
+        float xn[IN_CH];
+#pragma unroll
+        for (int k = 0; k < IN_CH; ++k)
+            xn[k] = (xi[k] - w.bn_rm[k]) / sqrtf(w.bn_rv[k] + 1e-5f) * w.bn_w[k] + w.bn_b[k];
+        float a[NC];
+        float s1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            float acc = 0.0f;
+            if (c < D) {
+#pragma unroll
+                for (int k = 0; k < IN_CH; ++k) acc += xn[k] * w.w_inT[k * D + c];
+                acc += w.b_in[c];
+                s1 += acc;
+            }
+            a[j] = acc;
+        }
+        const float mean = wave_sum(s1) / (float)D;
+        float s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) { const float d = a[j] - mean; s2 += d * d; }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)D + 1e-5f);
+        // prior booster hidden unit on lane q < Q
+        const float p0 = xi[IN_CH - 3], p1 = xi[IN_CH - 2], p2 = xi[IN_CH - 1];
+        float bq = 0.0f;
+        if (lane < Q) {
+            float acc = 0.0f;
+            acc += p0 * w.pb_w0[lane * 3 + 0];
+            acc += p1 * w.pb_w0[lane * 3 + 1];
+            acc += p2 * w.pb_w0[lane * 3 + 2];
+            bq = gelu_f(acc + w.pb_b0[lane]);
+        }
+        float g[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) g[j] = 0.0f;
+        for (int q = 0; q < Q; ++q) {
+            const float bv = __shfl(bq, q, 64);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int c = lane + 64 * j;
+                if (c < D) g[j] += bv * w.pb_w2T[q * D + c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) {
+                const float v = gelu_f((a[j] - mean) * rstd * w.ln_w[c] + w.ln_b[c]);
+                h[(size_t)node * D + c] = v * (1.0f + sigmoid_f(g[j] + w.pb_b2[c]));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------- M2: edge context
+struct EdgeW {
+    const float *w0 /*[C,5]*/, *b0, *w2T /*[C][C] in-major*/, *b2;
+    const float *ln_w, *ln_b, *wgT /*[C][D]*/, *bg;
+};
+
+template <int D>
+__global__ void __launch_bounds__(256) k_edge_gate(int N, const int32_t* __restrict__ row_ptr,
+                                                   const int32_t* __restrict__ eid,
+                                                   const float* __restrict__ edge_attr, EdgeW w, int C,
+                                                   float* __restrict__ gate) {
+    constexpr int NC = (D + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    float w0[EDGE_CH] = {0, 0, 0, 0, 0};
+    float b0 = 0.0f;
+    if (lane < C) {
+#pragma unroll
+        for (int k = 0; k < EDGE_CH; ++k) w0[k] = w.w0[lane * EDGE_CH + k];
+        b0 = w.b0[lane];
+    }
+    for (int node = wave; node < N; node += n_waves) {
+        const int beg = row_ptr[node], end = row_ptr[node + 1];
+        float sum = 0.0f;
+        for (int p = beg; p < end; ++p) {
+            const float* a = edge_attr + (size_t)eid[p] * EDGE_CH;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < EDGE_CH; ++k) acc += a[k] * w0[k];
+            sum += gelu_f(acc + b0);
+        }
+        const int cnt = end - beg;
+        // mean over incoming edges commutes with the second (linear) layer:
+        // mean_e(W2 e1_e + b2) = W2 mean_e(e1_e) + b2  (model.py:138, _scatter_mean :69-74)
+        const float m = sum / (float)(cnt > 0 ? cnt : 1);
+        float cv = 0.0f;
+        if (cnt > 0) {
+            float acc = 0.0f;
+            for (int k = 0; k < C; ++k) {
+                const float mk = __shfl(m, k, 64);
+                if (lane < C) acc += mk * w.w2T[k * C + lane];
+            }
+            if (lane < C) cv = acc + w.b2[lane];
+        }
+        const float mean = wave_sum(lane < C ? cv : 0.0f) / (float)C;
+        const float dv = (lane < C) ? cv - mean : 0.0f;
+        const float rstd = 1.0f / sqrtf(wave_sum(dv * dv) / (float)C + 1e-5f);
+        const float ln = (lane < C) ? dv * rstd * w.ln_w[lane] + w.ln_b[lane] : 0.0f;
+        float g[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) g[j] = 0.0f;
+        for (int k = 0; k < C; ++k) {
+            const float lk = __shfl(ln, k, 64);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int c = lane + 64 * j;
+                if (c < D) g[j] += lk * w.wgT[k * D + c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) gate[(size_t)node * D + c] = sigmoid_f(g[j] + w.bg[c]);
+        }
+    }
+}
+
+// ---------------------------------------------------------- M3/M4/M7: MFMA GEMM
+// out[N,D] = op(A)[N,D] @ W^T, f32 in / f32 accumulate on v_mfma_f32_32x32x2_f32.
+// A block is 4 waves; each wave owns 32 rows x D columns (T = D/32 accumulator
+// tiles).  The k index is permuted so that lane half hk = lane>>5 covers
+// k in [hk*D/2, (hk+1)*D/2): each lane then reads one contiguous half-row of A
+// (float4 loads) and W is pre-packed on the host as Wp[s/4][t][lane][s%4] =
+// W[32t + (lane&31)][hk*D/2 + s], staged once per block into LDS and read with
+// conflict-free ds_read_b128.
+//   MODE 0: A = LayerNorm(A1); store                                   (GCN XW)
+//   MODE 1: A1 @ W1^T + A2 @ W2^T + bias -> LayerNorm -> GELU          (SAGE)
+//   MODE 2: A = LayerNorm(A1 * gvec[batch]); + bias -> GELU -> head -> softmax
+struct GemmArgs {
+    const float *A1, *A2, *Wp1, *Wp2;
+    const float *ln_w, *ln_b;        // prologue LayerNorm
+    const float *bias;               // [D]
+    const int32_t* batch;            // MODE 2
+    const float* gvec;               // MODE 2: [G,D]
+    const float *ep_w, *ep_b;        // MODE 1: LN weight/bias; MODE 2: head weight [3,D] / bias [3]
+    float *out, *out2;               // MODE 2: logits / probs (either may be null)
+};
+
+template <int D, int MODE>
+__global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
+    constexpr int T = D / 32, KH = D / 2;
+    extern __shared__ float4 smem4[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = lane >> 5, li = lane & 31;
+    const int r0 = (blockIdx.x * 4 + wave) * 32;
+    const int row = min(r0 + li, N - 1);
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    constexpr int PHASES = (MODE == 1) ? 2 : 1;
+#pragma unroll
+    for (int ph = 0; ph < PHASES; ++ph) {
+        const float* Wp = ph ? g.Wp2 : g.Wp1;
+        const float* A = ph ? g.A2 : g.A1;
+        if (ph) __syncthreads();
+        for (int i = tid; i < D * D / 4; i += 256) smem4[i] = reinterpret_cast<const float4*>(Wp)[i];
+        __syncthreads();
+
+        float a[KH];
+        const float4* ap = reinterpret_cast<const float4*>(A + (size_t)row * D + hk * KH);
+#pragma unroll
+        for (int q = 0; q < KH / 4; ++q) {
+            const float4 v = ap[q];
+            a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+        }
+        if (MODE == 2) {
+            const float* gv = g.gvec + (size_t)g.batch[row] * D + hk * KH;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) a[s] *= gv[s];
+        }
+        if (MODE == 0 || MODE == 2) {
+            float s1 = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) s1 += a[s];
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mean = s1 / (float)D;
+            float s2 = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) { const float d = a[s] - mean; s2 += d * d; }
+            s2 += __shfl_xor(s2, 32, 64);
+            const float rstd = 1.0f / sqrtf(s2 / (float)D + 1e-5f);
+            const float* lw = g.ln_w + hk * KH;
+            const float* lb = g.ln_b + hk * KH;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) a[s] = (a[s] - mean) * rstd * lw[s] + lb[s];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < KH / 4; ++s4) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float4 b = smem4[(s4 * T + t) * 64 + lane];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 0], b.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 1], b.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 2], b.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 3], b.w, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // C/D layout: col = 32 t + (lane & 31), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    if (MODE == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int grow = r0 + (r & 3) + 8 * (r >> 2) + 4 * hk;
+            if (grow < N) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) g.out[(size_t)grow * D + 32 * t + li] = acc[t][r];
+            }
+        }
+    } else if (MODE == 1) {
+        float bias[T], lw[T], lb[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) { bias[t] = g.bias[32 * t + li]; lw[t] = g.ep_w[32 * t + li]; lb[t] = g.ep_b[32 * t + li]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s1 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) { acc[t][r] += bias[t]; s1 += acc[t][r]; }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            const float mean = s1 / (float)D;
+            float s2 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) { const float d = acc[t][r] - mean; s2 += d * d; }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            const float rstd = 1.0f / sqrtf(s2 / (float)D + 1e-5f);
+            const int grow = r0 + (r & 3) + 8 * (r >> 2) + 4 * hk;
+            if (grow < N) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    g.out[(size_t)grow * D + 32 * t + li] = gelu_f((acc[t][r] - mean) * rstd * lw[t] + lb[t]);
+            }
+        }
+    } else {
+        float bias[T], hw[N_CLS][T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            bias[t] = g.bias[32 * t + li];
+#pragma unroll
+            for (int c = 0; c < N_CLS; ++c) hw[c][t] = g.ep_w[c * D + 32 * t + li];
+        }
+        const float hb0 = g.ep_b[0], hb1 = g.ep_b[1], hb2 = g.ep_b[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p[N_CLS] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float v = gelu_f(acc[t][r] + bias[t]);
+#pragma unroll
+                for (int c = 0; c < N_CLS; ++c) p[c] += v * hw[c][t];
+            }
+#pragma unroll
+            for (int c = 0; c < N_CLS; ++c)
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) p[c] += __shfl_xor(p[c], o, 64);
+            const int grow = r0 + (r & 3) + 8 * (r >> 2) + 4 * hk;
+            if (li == 0 && grow < N) {
+                const float l0 = p[0] + hb0, l1 = p[1] + hb1, l2 = p[2] + hb2;
+                if (g.out) { g.out[(size_t)grow * 3 + 0] = l0; g.out[(size_t)grow * 3 + 1] = l1; g.out[(size_t)grow * 3 + 2] = l2; }
+                if (g.out2) {
+                    const float mx = fmaxf(l0, fmaxf(l1, l2));
+                    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
+                    const float s = (e0 + e1) + e2;
+                    g.out2[(size_t)grow * 3 + 0] = e0 / s; g.out2[(size_t)grow * 3 + 1] = e1 / s; g.out2[(size_t)grow * 3 + 2] = e2 / s;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------- M3/M4: CSR scatter-gather
+// Destination-major gather: LPR lanes x float4 cover one D-wide row, a wave
+// handles 64/LPR rows, a block of 4 waves handles RPB consecutive rows.  Blocks
+// are remapped so each XCD walks a contiguous range of rows (= whole images):
+// the ~11 re-reads of every xw row then hit that XCD's L2.  Neighbours are
+// summed in CSR (= edge) order with one rounding per multiply and per add, the
+// self loop last, exactly like the oracle.
+//   MODE 0 (GCNConv): out = sum dis[j] dis[i] xw[j] + dis[i]^2 xw[i] + bias,
+//                     fused epilogue h + gelu(out * gate) when gate != null.
+//   MODE 1 (SAGE mean): out = sum xw[j] / max(cnt, 1).
+template <int D> struct AggCfg {
+    static constexpr int LPR = (D <= 32) ? 8 : (D <= 64) ? 16 : 32;
+    static constexpr int RPW = 64 / LPR;
+    static constexpr int RPB = 4 * RPW;
+};
+
+__device__ __forceinline__ void fma4(float4& acc, float w, const float4& v) {
+    acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+}
+
+template <int D, int MODE>
+__global__ void __launch_bounds__(256) k_aggregate(int N, const float* __restrict__ xw,
+                                                   const int32_t* __restrict__ row_ptr,
+                                                   const int32_t* __restrict__ col,
+                                                   const float* __restrict__ dis,
+                                                   const float* __restrict__ bias,
+                                                   const float* __restrict__ gate,
+                                                   const float* __restrict__ h,
+                                                   float* __restrict__ out) {
+    constexpr int LPR = AggCfg<D>::LPR, RPW = AggCfg<D>::RPW, RPB = AggCfg<D>::RPB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int row = blk * RPB + wave * RPW + sub;
+    if (row >= N || sl * 4 >= D) return;
+    const int beg = row_ptr[row], end = row_ptr[row + 1];
+    const float di = (MODE == 0) ? dis[row] : 1.0f;
+    const float4* xw4 = reinterpret_cast<const float4*>(xw) + sl;
+    constexpr int D4 = D / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = beg;
+    for (; p + 4 <= end; p += 4) {
+        const int j0 = col[p], j1 = col[p + 1], j2 = col[p + 2], j3 = col[p + 3];
+        const float4 v0 = xw4[(size_t)j0 * D4], v1 = xw4[(size_t)j1 * D4];
+        const float4 v2 = xw4[(size_t)j2 * D4], v3 = xw4[(size_t)j3 * D4];
+        if (MODE == 0) {
+            const float w0 = dis[j0] * di, w1 = dis[j1] * di, w2 = dis[j2] * di, w3 = dis[j3] * di;
+            fma4(acc, w0, v0); fma4(acc, w1, v1); fma4(acc, w2, v2); fma4(acc, w3, v3);
+        } else {
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        }
+    }
+    for (; p < end; ++p) {
+        const int j = col[p];
+        const float4 v = xw4[(size_t)j * D4];
+        if (MODE == 0) fma4(acc, dis[j] * di, v);
+        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    }
+    const size_t o4 = (size_t)row * D4 + sl;
+    if (MODE == 0) {
+        fma4(acc, di * di, xw4[(size_t)row * D4]);
+        if (bias) {
+            const float4 b = reinterpret_cast<const float4*>(bias)[sl];
+            acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+        }
+        if (gate) {
+            const float4 gt = reinterpret_cast<const float4*>(gate)[o4];
+            const float4 hv = reinterpret_cast<const float4*>(h)[o4];
+            acc.x = hv.x + gelu_f(acc.x * gt.x); acc.y = hv.y + gelu_f(acc.y * gt.y);
+            acc.z = hv.z + gelu_f(acc.z * gt.z); acc.w = hv.w + gelu_f(acc.w * gt.w);
+        }
+    } else {
+        const int cnt = end - beg;
+        const float c = (float)(cnt > 0 ? cnt : 1);
+        acc.x /= c; acc.y /= c; acc.z /= c; acc.w /= c;
+    }
+    reinterpret_cast<float4*>(out)[o4] = acc;
+}
+
+// ----------------------------------------------------------------- M5: JK fusion
+// h_jk = sum_k softmax(jk_logits)_k * states[k]; score = attn . h_jk + b.
+template <int D>
+__global__ void __launch_bounds__(256) k_jk(int N, int n_states, const float* __restrict__ states,
+                                            const float* __restrict__ jk_w /*[n_states] softmaxed*/,
+                                            const float* __restrict__ attn_w, const float* __restrict__ attn_b,
+                                            float* __restrict__ hjk, float* __restrict__ score) {
+    constexpr int LPR = AggCfg<D>::LPR, RPW = AggCfg<D>::RPW, RPB = AggCfg<D>::RPB, D4 = D / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int row = blockIdx.x * RPB + wave * RPW + sub;
+    const bool act = row < N && sl * 4 < D;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dot = 0.0f;
+    if (act) {
+        const size_t o4 = (size_t)row * D4 + sl;
+        const size_t stride4 = (size_t)N * D4;
+        for (int k = 0; k < n_states; ++k) {
+            const float wk = jk_w[k];
+            const float4 v = reinterpret_cast<const float4*>(states)[o4 + stride4 * k];
+            acc.x += v.x * wk; acc.y += v.y * wk; acc.z += v.z * wk; acc.w += v.w * wk;
+        }
+        reinterpret_cast<float4*>(hjk)[o4] = acc;
+        const float4 aw = reinterpret_cast<const float4*>(attn_w)[sl];
+        dot = ((acc.x * aw.x + acc.y * aw.y) + acc.z * aw.z) + acc.w * aw.w;
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if (act && sl == 0) score[row] = dot + attn_b[0];
+}
+
+// ------------------------------------------------------ M6: per-graph readout
+struct CtxW { const float *wcT /*[D][D/2]*/, *bc, *weT /*[D/2][D]*/, *be; };
+
+template <int D>
+__global__ void __launch_bounds__(256) k_graph_ctx(const int32_t* __restrict__ node_ptr,
+                                                   const float* __restrict__ score,
+                                                   const float* __restrict__ hjk, CtxW w,
+                                                   float* __restrict__ gvec) {
+    constexpr int Dh = D / 2;
+    constexpr int NG = 256 / D;  // column groups (D <= 128 -> >= 2)
+    __shared__ float red[256];
+    __shared__ float gsum[D];
+    __shared__ float cbuf[Dh];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int beg = node_ptr[g], end = node_ptr[g + 1];
+    float m = -INFINITY;
+    for (int i = beg + tid; i < end; i += 256) m = fmaxf(m, score[i]);
+    red[tid] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    m = red[0];
+    __syncthreads();
+    float s = 0.0f;
+    for (int i = beg + tid; i < end; i += 256) s += expf(score[i] - m);
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float tot = red[0] + 1e-12f;  // model.py:108
+    __syncthreads();
+    const int d = tid % D, grp = tid / D;
+    float acc = 0.0f;
+    if (grp < NG)
+        for (int i = beg + grp; i < end; i += NG) acc += (expf(score[i] - m) / tot) * hjk[(size_t)i * D + d];
+    red[tid] = (grp < NG) ? acc : 0.0f;
+    __syncthreads();
+    if (tid < D) {
+        float v = 0.0f;
+        for (int q = 0; q < NG; ++q) v += red[q * D + tid];
+        gsum[tid] = v;
+    }
+    __syncthreads();
+    if (tid < Dh) {
+        float a = 0.0f;
+        for (int k = 0; k < D; ++k) a += gsum[k] * w.wcT[k * Dh + tid];
+        a += w.bc[tid];
+        cbuf[tid] = a > 0.0f ? a : 0.0f;
+    }
+    __syncthreads();
+    if (tid < D) {
+        float a = 0.0f;
+        for (int k = 0; k < Dh; ++k) a += cbuf[k] * w.weT[k * D + tid];
+        gvec[(size_t)g * D + tid] = sigmoid_f(a + w.be[tid]);
+    }
+}
+
+// ------------------------------------------------------------- weight handling
+
+static const float* devp(ggc_ctx* ctx, const std::string& k) {
+    auto it = ctx->model.dev.find(k);
+    return it == ctx->model.dev.end() ? nullptr : reinterpret_cast<const float*>(it->second.p);
+}
+
+static int upload(ggc_ctx* ctx, const std::string& key, const std::vector<float>& v) {
+    Buf& b = ctx->model.dev[key];
+    const size_t bytes = v.size() * sizeof(float);
+    if (b.bytes < bytes) {
+        if (b.p) GGC_HIP(ctx, hipFree(b.p));
+        b.p = nullptr; b.bytes = 0;
+        GGC_HIP(ctx, hipMalloc(&b.p, bytes ? bytes : 16));
+        b.bytes = bytes;
+    }
+    if (bytes) GGC_HIP(ctx, hipMemcpy(b.p, v.data(), bytes, hipMemcpyHostToDevice));
+    return GGC_OK;
+}
+
+static std::vector<float> transpose(const std::vector<float>& w, int out, int in) {
+    std::vector<float> t((size_t)out * in);
+    for (int o = 0; o < out; ++o)
+        for (int k = 0; k < in; ++k) t[(size_t)k * out + o] = w[(size_t)o * in + k];
+    return t;
+}
+
+// Wp[s/4][t][lane][s%4] = W[32 t + (lane & 31)][(lane >> 5) * D/2 + s]
+static std::vector<float> pack_mfma(const std::vector<float>& w, int D) {
+    const int T = D / 32, KH = D / 2;
+    std::vector<float> p((size_t)D * D);
+    for (int s = 0; s < KH; ++s)
+        for (int t = 0; t < T; ++t)
+            for (int l = 0; l < 64; ++l)
+                p[(((size_t)(s / 4) * T + t) * 64 + l) * 4 + (s % 4)] =
+                    w[(size_t)(32 * t + (l & 31)) * D + (l >> 5) * KH + s];
+    return p;
+}
+
+struct Need { std::string key; int64_t numel; };
+
+static std::vector<Need> needed(const ResgcnWeights& m) {
+    const int D = m.D, Q = m.Q, C = m.C, n = m.n_layers;
+    std::vector<Need> v = {
+        {"in_norm.norm.weight", IN_CH}, {"in_norm.norm.bias", IN_CH},
+        {"in_norm.norm.running_mean", IN_CH}, {"in_norm.norm.running_var", IN_CH},
+        {"input_proj.0.weight", (int64_t)D * IN_CH}, {"input_proj.0.bias", D},
+        {"input_proj.1.weight", D}, {"input_proj.1.bias", D},
+        {"prior_booster.0.weight", (int64_t)Q * N_PRIOR}, {"prior_booster.0.bias", Q},
+        {"prior_booster.2.weight", (int64_t)D * Q}, {"prior_booster.2.bias", D},
+        {"edge_ctx.encode.0.weight", (int64_t)C * EDGE_CH}, {"edge_ctx.encode.0.bias", C},
+        {"edge_ctx.encode.2.weight", (int64_t)C * C}, {"edge_ctx.encode.2.bias", C},
+        {"edge_ctx.to_gate.0.weight", C}, {"edge_ctx.to_gate.0.bias", C},
+        {"edge_ctx.to_gate.1.weight", (int64_t)D * C}, {"edge_ctx.to_gate.1.bias", D},
+        {"sage.lin_l.weight", (int64_t)D * D}, {"sage.lin_l.bias", D}, {"sage.lin_r.weight", (int64_t)D * D},
+        {"sage_norm.weight", D}, {"sage_norm.bias", D}, {"jk_logits", n + 2},
+        {"ctx.attn.weight", D}, {"ctx.attn.bias", 1},
+        {"ctx.compress.weight", (int64_t)(D / 2) * D}, {"ctx.compress.bias", D / 2},
+        {"ctx.expand.weight", (int64_t)D * (D / 2)}, {"ctx.expand.bias", D},
+        {"fuse.0.weight", D}, {"fuse.0.bias", D}, {"fuse.1.weight", (int64_t)D * D}, {"fuse.1.bias", D},
+        {"head.weight", (int64_t)N_CLS * D}, {"head.bias", N_CLS},
+    };
+    for (int i = 0; i < n; ++i) {
+        const std::string s = std::to_string(i);
+        v.push_back({"gcn_layers." + s + ".bias", D});
+        v.push_back({"gcn_layers." + s + ".lin.weight", (int64_t)D * D});
+        v.push_back({"norms." + s + ".weight", D});
+        v.push_back({"norms." + s + ".bias", D});
+    }
+    return v;
+}
+
+static int check_ready(ggc_ctx* ctx) {
+    ResgcnWeights& m = ctx->model;
+    GGC_REQUIRE(ctx, m.D > 0, GGC_E_STATE, "ggc_resgcn_configure has not been called");
+    for (const Need& nd : needed(m)) {
+        auto it = m.host.find(nd.key);
+        GGC_REQUIRE(ctx, it != m.host.end(), GGC_E_STATE, "missing weight '%s'", nd.key.c_str());
+        GGC_REQUIRE(ctx, (int64_t)it->second.size() == nd.numel, GGC_E_SHAPE,
+                    "weight '%s' has %zu elements, expected %lld", nd.key.c_str(), it->second.size(),
+                    (long long)nd.numel);
+    }
+    return GGC_OK;
+}
+
+static int prepare_weights(ggc_ctx* ctx) {
+    ResgcnWeights& m = ctx->model;
+    if (m.dev_ok) return GGC_OK;
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    const int D = m.D, Q = m.Q, C = m.C, n = m.n_layers;
+    for (auto& kv : m.host) { rc = upload(ctx, kv.first, kv.second); if (rc) return rc; }
+    if ((rc = upload(ctx, "#input_proj.0.weightT", transpose(m.host["input_proj.0.weight"], D, IN_CH)))) return rc;
+    if ((rc = upload(ctx, "#prior_booster.2.weightT", transpose(m.host["prior_booster.2.weight"], D, Q)))) return rc;
+    if ((rc = upload(ctx, "#edge_ctx.encode.2.weightT", transpose(m.host["edge_ctx.encode.2.weight"], C, C)))) return rc;
+    if ((rc = upload(ctx, "#edge_ctx.to_gate.1.weightT", transpose(m.host["edge_ctx.to_gate.1.weight"], D, C)))) return rc;
+    if ((rc = upload(ctx, "#ctx.compress.weightT", transpose(m.host["ctx.compress.weight"], D / 2, D)))) return rc;
+    if ((rc = upload(ctx, "#ctx.expand.weightT", transpose(m.host["ctx.expand.weight"], D, D / 2)))) return rc;
+    for (int i = 0; i < n; ++i) {
+        const std::string k = "gcn_layers." + std::to_string(i) + ".lin.weight";
+        if ((rc = upload(ctx, "#" + k + ".p", pack_mfma(m.host[k], D)))) return rc;
+    }
+    if ((rc = upload(ctx, "#sage.lin_l.weight.p", pack_mfma(m.host["sage.lin_l.weight"], D)))) return rc;
+    if ((rc = upload(ctx, "#sage.lin_r.weight.p", pack_mfma(m.host["sage.lin_r.weight"], D)))) return rc;
+    if ((rc = upload(ctx, "#fuse.1.weight.p", pack_mfma(m.host["fuse.1.weight"], D)))) return rc;
+    {   // softmax(jk_logits) on the host (model.py:532), same op order as the oracle
+        const std::vector<float>& jl = m.host["jk_logits"];
+        std::vector<float> w(jl.size());
+        float mx = jl[0];
+        for (float v : jl) mx = v > mx ? v : mx;
+        float s = 0.0f;
+        for (size_t k = 0; k < jl.size(); ++k) { w[k] = expf(jl[k] - mx); s += w[k]; }
+        for (size_t k = 0; k < jl.size(); ++k) w[k] = w[k] / s;
+        if ((rc = upload(ctx, "#jk_w", w))) return rc;
+    }
+    m.dev_ok = true;
+    return GGC_OK;
+}
+
+// ------------------------------------------------------------ launch helpers
+
+template <int D, int MODE>
+static int launch_gemm(ggc_ctx* ctx, hipStream_t st, int N, const GemmArgs& a) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)D * D * sizeof(float);
+    if (!attr_set && lds > 48 * 1024) {
+        GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<D, MODE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm<D, MODE>), dim3(cdiv(N, 128)), dim3(256), lds, st, N, a);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
+
+template <int D, int MODE>
+static int launch_aggregate(ggc_ctx* ctx, hipStream_t st, int N, const float* xw, const int32_t* row_ptr,
+                            const int32_t* col, const float* dis, const float* bias, const float* gate,
+                            const float* h, float* out) {
+    hipLaunchKernelGGL((k_aggregate<D, MODE>), dim3(cdiv(N, AggCfg<D>::RPB)), dim3(256), 0, st,
+                       N, xw, row_ptr, col, dis, bias, gate, h, out);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
+
+template <int D>
+static int forward_t(ggc_ctx* ctx, hipStream_t st, int G, int N, int E, const float* x,
+                     const int32_t* edge_src, const int32_t* edge_dst, const float* edge_attr,
+                     const int32_t* node_ptr, float* logits, float* probs) {
+    ResgcnWeights& m = ctx->model;
+    const int n = m.n_layers, n_states = n + 2;
+    const size_t ND = (size_t)N * D;
+    int32_t* row_ptr = scratch_t<int32_t>(ctx, S_CSR_ROWPTR, (size_t)N + 1);
+    int32_t* col = scratch_t<int32_t>(ctx, S_CSR_COL, (size_t)E);
+    int32_t* eid = scratch_t<int32_t>(ctx, S_CSR_EID, (size_t)E);
+    int32_t* cursor = scratch_t<int32_t>(ctx, S_CSR_CURSOR, (size_t)N + 1);
+    float* dis = scratch_t<float>(ctx, S_DIS, (size_t)N);
+    int32_t* batch = scratch_t<int32_t>(ctx, S_BATCH, (size_t)N);
+    float* states = scratch_t<float>(ctx, S_STATES, ND * n_states);
+    float* gate = scratch_t<float>(ctx, S_GATE, ND);
+    float* xw = scratch_t<float>(ctx, S_XW, ND);
+    float* agg = scratch_t<float>(ctx, S_AGG, ND);
+    float* hjk = scratch_t<float>(ctx, S_HJK, ND);
+    float* score = scratch_t<float>(ctx, S_SCORE, (size_t)N);
+    float* gvec = scratch_t<float>(ctx, S_GVEC, (size_t)G * D);
+    if (!row_ptr || !col || !eid || !cursor || !dis || !batch || !states || !gate || !xw || !agg || !hjk ||
+        !score || !gvec)
+        return GGC_E_OOM;
+
+    int rc = build_csr(ctx, st, N, E, edge_src, edge_dst, row_ptr, col, eid, cursor, dis);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fill_batch, dim3(min(cdiv(N, 256), 4096)), dim3(256), 0, st, G, N, node_ptr, batch);
+    GGC_LAUNCH_CHECK(ctx);
+
+    const int wave_blocks = min(cdiv(N, 4), 8 * ctx->n_cu);
+    {
+        InputW w{devp(ctx, "in_norm.norm.weight"), devp(ctx, "in_norm.norm.bias"),
+                 devp(ctx, "in_norm.norm.running_mean"), devp(ctx, "in_norm.norm.running_var"),
+                 devp(ctx, "#input_proj.0.weightT"), devp(ctx, "input_proj.0.bias"),
+                 devp(ctx, "input_proj.1.weight"), devp(ctx, "input_proj.1.bias"),
+                 devp(ctx, "prior_booster.0.weight"), devp(ctx, "prior_booster.0.bias"),
+                 devp(ctx, "#prior_booster.2.weightT"), devp(ctx, "prior_booster.2.bias")};
+        hipLaunchKernelGGL((k_input<D>), dim3(wave_blocks), dim3(256), 0, st, N, x, w, m.Q, states);
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    {
+        EdgeW w{devp(ctx, "edge_ctx.encode.0.weight"), devp(ctx, "edge_ctx.encode.0.bias"),
+                devp(ctx, "#edge_ctx.encode.2.weightT"), devp(ctx, "edge_ctx.encode.2.bias"),
+                devp(ctx, "edge_ctx.to_gate.0.weight"), devp(ctx, "edge_ctx.to_gate.0.bias"),
+                devp(ctx, "#edge_ctx.to_gate.1.weightT"), devp(ctx, "edge_ctx.to_gate.1.bias")};
+        hipLaunchKernelGGL((k_edge_gate<D>), dim3(wave_blocks), dim3(256), 0, st, N, row_ptr, eid, edge_attr, w,
+                           m.C, gate);
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    for (int l = 0; l < n; ++l) {
+        const std::string s = std::to_string(l);
+        const float* h_in = states + ND * l;
+        float* h_out = states + ND * (l + 1);
+        GemmArgs a{};
+        a.A1 = h_in; a.Wp1 = devp(ctx, "#gcn_layers." + s + ".lin.weight.p");
+        a.ln_w = devp(ctx, "norms." + s + ".weight"); a.ln_b = devp(ctx, "norms." + s + ".bias");
+        a.out = xw;
+        if ((rc = launch_gemm<D, 0>(ctx, st, N, a))) return rc;
+        if ((rc = launch_aggregate<D, 0>(ctx, st, N, xw, row_ptr, col, dis, devp(ctx, "gcn_layers." + s + ".bias"),
+                                         gate, h_in, h_out)))
+            return rc;
+    }
+    {
+        const float* hl = states + ND * n;
+        if ((rc = launch_aggregate<D, 1>(ctx, st, N, hl, row_ptr, col, nullptr, nullptr, nullptr, nullptr, agg)))
+            return rc;
+        GemmArgs a{};
+        a.A1 = agg; a.A2 = hl;
+        a.Wp1 = devp(ctx, "#sage.lin_l.weight.p"); a.Wp2 = devp(ctx, "#sage.lin_r.weight.p");
+        a.bias = devp(ctx, "sage.lin_l.bias");
+        a.ep_w = devp(ctx, "sage_norm.weight"); a.ep_b = devp(ctx, "sage_norm.bias");
+        a.out = states + ND * (n + 1);
+        if ((rc = launch_gemm<D, 1>(ctx, st, N, a))) return rc;
+    }
+    hipLaunchKernelGGL((k_jk<D>), dim3(cdiv(N, AggCfg<D>::RPB)), dim3(256), 0, st, N, n_states, states,
+                       devp(ctx, "#jk_w"), devp(ctx, "ctx.attn.weight"), devp(ctx, "ctx.attn.bias"), hjk, score);
+    GGC_LAUNCH_CHECK(ctx);
+    {
+        CtxW w{devp(ctx, "#ctx.compress.weightT"), devp(ctx, "ctx.compress.bias"),
+               devp(ctx, "#ctx.expand.weightT"), devp(ctx, "ctx.expand.bias")};
+        hipLaunchKernelGGL((k_graph_ctx<D>), dim3(G), dim3(256), 0, st, node_ptr, score, hjk, w, gvec);
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    {
+        GemmArgs a{};
+        a.A1 = hjk; a.Wp1 = devp(ctx, "#fuse.1.weight.p");
+        a.ln_w = devp(ctx, "fuse.0.weight"); a.ln_b = devp(ctx, "fuse.0.bias");
+        a.bias = devp(ctx, "fuse.1.bias");
+        a.batch = batch; a.gvec = gvec;
+        a.ep_w = devp(ctx, "head.weight"); a.ep_b = devp(ctx, "head.bias");
+        a.out = logits; a.out2 = probs;
+        if ((rc = launch_gemm<D, 2>(ctx, st, N, a))) return rc;
+    }
+    return GGC_OK;
+}
+
+} // namespace ggc
+
+using namespace ggc;
+
+extern "C" {
+
+int ggc_resgcn_configure(ggc_ctx* ctx, int hidden, int n_layers) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, hidden == 32 || hidden == 64 || hidden == 96 || hidden == 128, GGC_E_UNSUPPORTED,
+                "hidden_channels=%d unsupported: the MFMA tiling needs a multiple of 32 up to 128", hidden);
+    GGC_REQUIRE(ctx, n_layers >= 1 && n_layers <= 30, GGC_E_INVALID_ARG, "n_layers=%d out of range [1,30]", n_layers);
+    ResgcnWeights& m = ctx->model;
+    if (m.D != hidden || m.n_layers != n_layers) { m.host.clear(); }
+    m.D = hidden; m.n_layers = n_layers;
+    m.Q = hidden / 4 > 8 ? hidden / 4 : 8;   // model.py:472
+    m.C = hidden / 2 > 8 ? hidden / 2 : 8;   // model.py:123
+    m.dev_ok = false;
+    return GGC_OK;
+}
+
+int ggc_resgcn_load_weight(ggc_ctx* ctx, const char* name, const float* data, int64_t numel) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, name && (data || numel == 0) && numel >= 0, GGC_E_INVALID_ARG, "bad weight arguments");
+    GGC_REQUIRE(ctx, ctx->model.D > 0, GGC_E_STATE, "ggc_resgcn_configure has not been called");
+    const std::string key(name);
+    const std::string tail = "num_batches_tracked";
+    if (key.size() >= tail.size() && key.compare(key.size() - tail.size(), tail.size(), tail) == 0) return GGC_OK;
+    bool known = false;
+    for (const Need& nd : needed(ctx->model))
+        if (nd.key == key) {
+            GGC_REQUIRE(ctx, nd.numel == numel, GGC_E_SHAPE, "weight '%s' has %lld elements, expected %lld", name,
+                        (long long)numel, (long long)nd.numel);
+            known = true;
+            break;
+        }
+    GGC_REQUIRE(ctx, known, GGC_E_INVALID_ARG, "unexpected state_dict key '%s' for ResGCNNet(D=%d, n=%d)", name,
+                ctx->model.D, ctx->model.n_layers);
+    ctx->model.host[key].assign(data, data + numel);
+    ctx->model.dev_ok = false;
+    return GGC_OK;
+}
+
+int ggc_resgcn_ready(ggc_ctx* ctx) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    return check_ready(ctx);
+}
+
+int ggc_resgcn_forward(ggc_ctx* ctx, ggc_stream stream, int G, int N, int E, const float* x,
+                       const int32_t* edge_src, const int32_t* edge_dst, const float* edge_attr,
+                       const int32_t* node_ptr, float* logits, float* probs) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, G >= 1 && N >= 1 && E >= 0, GGC_E_SHAPE, "bad sizes G=%d N=%d E=%d", G, N, E);
+    GGC_REQUIRE(ctx, x && node_ptr && (E == 0 || (edge_src && edge_dst && edge_attr)), GGC_E_INVALID_ARG,
+                "null input pointer");
+    GGC_REQUIRE(ctx, logits || probs, GGC_E_INVALID_ARG, "both outputs are NULL");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = prepare_weights(ctx);
+    if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (ctx->model.D) {
+        case 32:  return forward_t<32>(ctx, st, G, N, E, x, edge_src, edge_dst, edge_attr, node_ptr, logits, probs);
+        case 64:  return forward_t<64>(ctx, st, G, N, E, x, edge_src, edge_dst, edge_attr, node_ptr, logits, probs);
+        case 96:  return forward_t<96>(ctx, st, G, N, E, x, edge_src, edge_dst, edge_attr, node_ptr, logits, probs);
+        case 128: return forward_t<128>(ctx, st, G, N, E, x, edge_src, edge_dst, edge_attr, node_ptr, logits, probs);
+    }
+    return set_err(ctx, GGC_E_UNSUPPORTED, "hidden=%d", ctx->model.D);
+}
+
+int ggc_build_csr(ggc_ctx* ctx, ggc_stream stream, int N, int E, const int32_t* edge_src,
+                  const int32_t* edge_dst, int32_t* row_ptr, int32_t* col, float* dis) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, N >= 1 && E >= 0 && row_ptr && (E == 0 || (edge_src && edge_dst && col)), GGC_E_INVALID_ARG,
+                "bad arguments");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t* eid = scratch_t<int32_t>(ctx, S_CSR_EID, (size_t)E);
+    int32_t* cursor = scratch_t<int32_t>(ctx, S_CSR_CURSOR, (size_t)N + 1);
+    if (!eid || !cursor) return GGC_E_OOM;
+    return build_csr(ctx, reinterpret_cast<hipStream_t>(stream), N, E, edge_src, edge_dst, row_ptr, col, eid,
+                     cursor, dis);
+}
+
+int ggc_gcn_aggregate(ggc_ctx* ctx, ggc_stream stream, int N, int D, const float* xw,
+                      const int32_t* row_ptr, const int32_t* col, const float* dis, const float* bias,
+                      const float* gate, const float* h, float* h_out) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, N >= 1 && xw && row_ptr && col && dis && h_out, GGC_E_INVALID_ARG, "bad arguments");
+    GGC_REQUIRE(ctx, (gate == nullptr) == (h == nullptr), GGC_E_INVALID_ARG, "gate and h must be given together");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (D) {
+        case 32:  return launch_aggregate<32, 0>(ctx, st, N, xw, row_ptr, col, dis, bias, gate, h, h_out);
+        case 64:  return launch_aggregate<64, 0>(ctx, st, N, xw, row_ptr, col, dis, bias, gate, h, h_out);
+        case 96:  return launch_aggregate<96, 0>(ctx, st, N, xw, row_ptr, col, dis, bias, gate, h, h_out);
+        case 128: return launch_aggregate<128, 0>(ctx, st, N, xw, row_ptr, col, dis, bias, gate, h, h_out);
+    }
+    return set_err(ctx, GGC_E_UNSUPPORTED, "D=%d unsupported (32, 64, 96, 128)", D);
+}
+
+} // extern "C"

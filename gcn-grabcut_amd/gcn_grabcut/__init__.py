@@ -1,0 +1,22 @@
+"""
+GCN-GrabCut on MI355X — host mirror of the reference package src/gcn_grabcut.
+
+Same public names as the reference (__init__.py:57-81) for the per-image
+segmentation hot path; all arithmetic runs in libggc_hip.so (hand-written
+gfx950 kernels behind the C ABI of include/ggc.h).  Training, datasets and
+plotting are out of scope.
+"""
+from ._constants import N_NODE_FEATS, N_EDGE_FEATS, N_PRIOR_FEATS, N_IMAGE_FEATS
+from .data import Data, Batch
+from .model import (
+    ResGCNNet, build_model, _probs_to_trimap, probs_to_node_trimap, project_to_pixels,
+    TRIMAP_BG, TRIMAP_FG, TRIMAP_PROB_BG, TRIMAP_PROB_FG, CLASS_BG, CLASS_UNK, CLASS_FG,
+)
+
+__version__ = "0.3.0+mi355x.1"
+
+__all__ = [
+    "N_NODE_FEATS", "N_EDGE_FEATS", "N_PRIOR_FEATS",
+    "Data", "Batch",
+    "ResGCNNet", "build_model", "probs_to_node_trimap", "project_to_pixels",
+]

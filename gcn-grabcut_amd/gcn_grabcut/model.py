@@ -1,0 +1,297 @@
+"""
+Trimap network — host mirror of reference src/gcn_grabcut/model.py.
+
+`ResGCNNet` keeps the reference's constructor, state_dict keys (model.py:449-499,
+SURVEY section 8 row M0) and methods (`forward`, `predict_probs`, `predict_trimap`,
+`layer_weights`, `param_groups`), but owns no arithmetic: the torch submodules
+below are parameter containers only, and `forward` hands raw device pointers
+to libggc_hip.so (ggc_resgcn_forward), whose kernels implement model.py:508-536
+on the MI355X.  Inference only (eval mode); there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+try:
+    import torch
+    import torch.nn as nn
+    _TORCH = True
+except ImportError:  # pragma: no cover
+    _TORCH = False
+
+from ._constants import N_NODE_FEATS, N_EDGE_FEATS, N_PRIOR_FEATS
+
+TRIMAP_BG = 0        # cv2.GC_BGD
+TRIMAP_FG = 1        # cv2.GC_FGD
+TRIMAP_PROB_BG = 2   # cv2.GC_PR_BGD
+TRIMAP_PROB_FG = 3   # cv2.GC_PR_FGD
+
+CLASS_BG = 0
+CLASS_UNK = 1
+CLASS_FG = 2
+
+
+if _TORCH:
+    from . import _native
+
+    class _InputNorm(nn.Module):
+        """Parameter holder for reference InputNorm (model.py:191-213)."""
+        def __init__(self, n_features: int, momentum: float = 0.05):
+            super().__init__()
+            self.norm = nn.BatchNorm1d(n_features, momentum=momentum, affine=True)
+
+    class _EdgeContext(nn.Module):
+        """Parameter holder for reference EdgeContext (model.py:111-139)."""
+        def __init__(self, edge_dim: int, hidden_dim: int, ctx_dim: Optional[int] = None):
+            super().__init__()
+            ctx_dim = ctx_dim or max(hidden_dim // 2, 8)
+            self.encode = nn.Sequential(nn.Linear(edge_dim, ctx_dim), nn.GELU(), nn.Linear(ctx_dim, ctx_dim))
+            self.to_gate = nn.Sequential(nn.LayerNorm(ctx_dim), nn.Linear(ctx_dim, hidden_dim), nn.Sigmoid())
+
+    class _GlobalContext(nn.Module):
+        """Parameter holder for reference GlobalContextModule (model.py:165-188)."""
+        def __init__(self, hidden_dim: int):
+            super().__init__()
+            self.attn = nn.Linear(hidden_dim, 1)
+            self.compress = nn.Linear(hidden_dim, hidden_dim // 2)
+            self.expand = nn.Linear(hidden_dim // 2, hidden_dim)
+
+    class _GCNConvParams(nn.Module):
+        """state_dict layout of PyG GCNConv(D, D): `lin.weight` [D,D], `bias` [D]."""
+        def __init__(self, dim: int):
+            super().__init__()
+            self.lin = nn.Linear(dim, dim, bias=False)
+            self.bias = nn.Parameter(torch.zeros(dim))
+
+    class _SAGEConvParams(nn.Module):
+        """state_dict layout of PyG SAGEConv(D, D): `lin_l.{weight,bias}`, `lin_r.weight`."""
+        def __init__(self, dim: int):
+            super().__init__()
+            self.lin_l = nn.Linear(dim, dim, bias=True)
+            self.lin_r = nn.Linear(dim, dim, bias=False)
+
+    class ResGCNNet(nn.Module):
+        """
+        Residual GCN with jumping-knowledge fusion (reference model.py:421-590),
+        executed by hand-written gfx950 kernels.
+
+        InputNorm -> InputProj -> PriorBooster -> [ResBlock x n_layers] ->
+        SAGEConv -> JK fusion -> GlobalContext -> Head
+        """
+
+        def __init__(
+            self,
+            in_channels: int = N_NODE_FEATS,
+            edge_channels: int = N_EDGE_FEATS,
+            hidden_channels: int = 128,
+            n_layers: int = 6,
+            n_classes: int = 3,
+            dropout: float = 0.15,
+        ):
+            super().__init__()
+            if in_channels != N_NODE_FEATS or edge_channels != N_EDGE_FEATS or n_classes != 3:
+                raise ValueError(
+                    "the MI355X kernels are specialised for the reference's fixed widths: "
+                    f"in_channels={N_NODE_FEATS}, edge_channels={N_EDGE_FEATS}, n_classes=3"
+                )
+            if hidden_channels not in (32, 64, 96, 128):
+                raise ValueError("hidden_channels must be 32, 64, 96 or 128 (MFMA tiling)")
+            self.n_classes = n_classes
+            self.n_layers = n_layers
+            self.hidden_channels = hidden_channels
+            D = hidden_channels
+
+            self.in_norm = _InputNorm(in_channels)
+            self.input_proj = nn.Sequential(nn.Linear(in_channels, D), nn.LayerNorm(D), nn.GELU())
+            self.prior_booster = nn.Sequential(
+                nn.Linear(N_PRIOR_FEATS, max(D // 4, 8)), nn.GELU(),
+                nn.Linear(max(D // 4, 8), D), nn.Sigmoid(),
+            )
+            self.edge_ctx = _EdgeContext(edge_channels, D)
+            self.gcn_layers = nn.ModuleList(_GCNConvParams(D) for _ in range(n_layers))
+            self.norms = nn.ModuleList(nn.LayerNorm(D) for _ in range(n_layers))
+            self.sage = _SAGEConvParams(D)
+            self.sage_norm = nn.LayerNorm(D)
+            self.jk_logits = nn.Parameter(torch.zeros(n_layers + 2))
+            self.ctx = _GlobalContext(D)
+            self.fuse = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, D), nn.GELU(), nn.Dropout(dropout))
+            self.head = nn.Linear(D, n_classes)
+            self.dropout = dropout
+            self._init_weights()
+            self._uploaded = None      # (ctx id, fingerprint) of the weights resident in the library
+
+        def _init_weights(self):
+            # reference model.py:501-506
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.kaiming_normal_(m.weight, nonlinearity="relu")
+                    if m.bias is not None:
+                        nn.init.zeros_(m.bias)
+
+        # ---------------------------------------------------------------- native
+
+        def _device_index(self) -> int:
+            dev = self.jk_logits.device
+            if dev.type != "cuda":
+                raise RuntimeError(
+                    "ResGCNNet runs on an MI355X through libggc_hip.so only; "
+                    f"the model is on '{dev}'. Move it with .to('cuda') — there is no CPU fallback."
+                )
+            return dev.index if dev.index is not None else torch.cuda.current_device()
+
+        def _sync_weights(self, ctx: "_native.Context") -> None:
+            sd = self.state_dict()
+            fp = (id(ctx), tuple((k, v.data_ptr(), v._version) for k, v in sd.items()))
+            if self._uploaded == fp:
+                return
+            ctx.call("ggc_resgcn_configure", self.hidden_channels, self.n_layers)
+            for k, v in sd.items():
+                if not v.dtype.is_floating_point:
+                    continue   # num_batches_tracked
+                a = v.detach().to(device="cpu", dtype=torch.float32).contiguous().numpy()
+                ctx.call("ggc_resgcn_load_weight", k.encode(), a.ctypes.data, a.size)
+            ctx.call("ggc_resgcn_ready")
+            self._uploaded = fp
+
+        def _run(self, data, want_logits: bool, want_probs: bool):
+            if self.training:
+                raise RuntimeError("ResGCNNet on MI355X is inference-only: call .eval() first "
+                                   "(training lives in the reference and is out of scope here)")
+            dev_index = self._device_index()
+            ctx = _native.get_context(dev_index)
+            self._sync_weights(ctx)
+            dev = torch.device("cuda", dev_index)
+
+            x = data.x
+            if x.device != dev:
+                raise RuntimeError(f"data.x is on {x.device}, model on {dev}")
+            x = x.to(torch.float32).contiguous()
+            n = x.size(0)
+            if x.dim() != 2 or x.size(1) != N_NODE_FEATS:
+                raise ValueError(f"data.x must be (N, {N_NODE_FEATS}), got {tuple(x.shape)}")
+            ei = data.edge_index
+            e = ei.size(1)
+            edge_attr = getattr(data, "edge_attr", None)
+            if edge_attr is None:                      # reference model.py:511-512
+                edge_attr = torch.zeros(e, N_EDGE_FEATS, device=dev)
+            edge_attr = edge_attr.to(torch.float32).contiguous()
+            src = ei[0].to(torch.int32).contiguous()
+            dst = ei[1].to(torch.int32).contiguous()
+
+            batch = getattr(data, "batch", None)
+            node_ptr = getattr(data, "node_ptr32", None)
+            if node_ptr is None:
+                if batch is None:
+                    node_ptr = torch.tensor([0, n], dtype=torch.int32, device=dev)
+                else:
+                    n_graphs = getattr(data, "num_graphs", None)
+                    if n_graphs is None:
+                        n_graphs = int(batch.max().item()) + 1   # reference model.py:86
+                    counts = torch.bincount(batch, minlength=n_graphs)
+                    node_ptr = torch.zeros(n_graphs + 1, dtype=torch.int32, device=dev)
+                    node_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            g = node_ptr.numel() - 1
+
+            logits = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_logits else None
+            probs = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_probs else None
+            ctx.call(
+                "ggc_resgcn_forward", _native.current_stream(dev_index), g, n, e,
+                x.data_ptr(), src.data_ptr(), dst.data_ptr(), edge_attr.data_ptr(), node_ptr.data_ptr(),
+                _native.ptr(logits), _native.ptr(probs),
+            )
+            return logits, probs
+
+        def forward(self, data) -> "torch.Tensor":
+            """logits (N, 3) on the model's device — reference model.py:508-536."""
+            with torch.no_grad():
+                return self._run(data, True, False)[0]
+
+        @torch.no_grad()
+        def layer_weights(self) -> np.ndarray:
+            """Fusion weights over [input, block 1..n, SAGE branch] (model.py:538-541)."""
+            return torch.softmax(self.jk_logits.detach(), dim=0).cpu().numpy()
+
+        @torch.no_grad()
+        def predict_probs(self, data) -> np.ndarray:
+            """softmax(logits) as a host array (model.py:543-546)."""
+            self.eval()
+            return self._run(data, False, True)[1].float().cpu().numpy()
+
+        @torch.no_grad()
+        def predict_probs_device(self, data) -> "torch.Tensor":
+            """Additive: like predict_probs but the result stays in HBM."""
+            self.eval()
+            return self._run(data, False, True)[1]
+
+        @torch.no_grad()
+        def predict_trimap(self, data, segments: np.ndarray,
+                           threshold_fg: float = 0.55, threshold_bg: float = 0.55) -> np.ndarray:
+            return _probs_to_trimap(self.predict_probs(data), segments, threshold_fg, threshold_bg)
+
+        def param_groups(self, base_lr: float) -> list[dict]:
+            """Layer-wise learning-rate decay groups (model.py:559-590); kept for API parity."""
+            groups = []
+            n = self.n_layers
+            for i, (gcn, norm) in enumerate(zip(self.gcn_layers, self.norms)):
+                groups.append({"params": list(gcn.parameters()) + list(norm.parameters()),
+                               "lr": base_lr * (0.8 ** (n - i))})
+            groups.append({"params": (list(self.in_norm.parameters()) + list(self.input_proj.parameters()) +
+                                      list(self.prior_booster.parameters())), "lr": base_lr * 0.5})
+            groups.append({"params": (list(self.edge_ctx.parameters()) + list(self.sage.parameters()) +
+                                      list(self.sage_norm.parameters()) + list(self.ctx.parameters())),
+                           "lr": base_lr * 0.9})
+            groups.append({"params": ([self.jk_logits] + list(self.fuse.parameters()) +
+                                      list(self.head.parameters())), "lr": base_lr})
+            return groups
+
+    def build_model(
+        variant: str = "resgcn",
+        in_channels: int = N_NODE_FEATS,
+        edge_channels: int = N_EDGE_FEATS,
+        hidden_channels: int = 128,
+        n_layers: int = 6,
+        n_classes: int = 3,
+        dropout: float = 0.2,
+    ) -> "nn.Module":
+        """Factory by name (reference model.py:593-620). Only "resgcn" is on the MI355X hot path."""
+        if variant == "resgcn":
+            return ResGCNNet(in_channels=in_channels, edge_channels=edge_channels,
+                             hidden_channels=hidden_channels, n_layers=n_layers,
+                             n_classes=n_classes, dropout=dropout)
+        if variant in ("gat", "gcn"):
+            raise NotImplementedError(
+                f"variant '{variant}' is not part of the MI355X hot path (SURVEY section 8(f)); use 'resgcn'")
+        raise ValueError(f"Unknown variant '{variant}'. Choose: resgcn | gcn | gat")
+
+
+def probs_to_node_trimap(probs: np.ndarray, threshold_fg: float = 0.55,
+                         threshold_bg: float = 0.55) -> np.ndarray:
+    """Per-region GrabCut labels from class probabilities (reference model.py:623-645)."""
+    bg_p, fg_p = probs[:, CLASS_BG], probs[:, CLASS_FG]
+    labels = np.where(fg_p > bg_p, TRIMAP_PROB_FG, TRIMAP_PROB_BG).astype(np.uint8)
+    labels[bg_p >= threshold_bg] = TRIMAP_BG
+    labels[fg_p >= threshold_fg] = TRIMAP_FG
+    return labels
+
+
+def project_to_pixels(node_values: np.ndarray, segments: np.ndarray) -> np.ndarray:
+    """values[segments] with zero padding for missing regions (reference model.py:648-661)."""
+    n_needed = int(segments.max()) + 1
+    values = node_values
+    if values.shape[0] < n_needed:
+        pad = np.zeros((n_needed - values.shape[0], *values.shape[1:]), dtype=values.dtype)
+        values = np.concatenate([values, pad], axis=0)
+    return values[segments]
+
+
+def _probs_to_trimap(probs: np.ndarray, segments: np.ndarray,
+                     threshold_fg: float, threshold_bg: float) -> np.ndarray:
+    """Pixel trimap without the guided filter (reference model.py:664-678)."""
+    node_labels = probs_to_node_trimap(probs, threshold_fg, threshold_bg)
+    n_needed = int(segments.max()) + 1
+    if node_labels.shape[0] < n_needed:
+        node_labels = np.concatenate([
+            node_labels, np.full(n_needed - node_labels.shape[0], TRIMAP_PROB_BG, dtype=np.uint8)])
+    return node_labels[segments].astype(np.uint8)

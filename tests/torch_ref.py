@@ -1,0 +1,86 @@
+"""
+PyG-free torch-CPU restatement of ResGCNNet.forward (reference model.py:508-536)
+used to pin the C oracle.  GCNConv / SAGEConv follow SURVEY.md Appendix A.3.
+Test infrastructure only.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def gcn_conv(x, edge_index, weight, bias):
+    n = x.size(0)
+    xw = x @ weight.t()
+    loops = torch.arange(n, dtype=edge_index.dtype)
+    src = torch.cat([edge_index[0], loops])
+    dst = torch.cat([edge_index[1], loops])
+    deg = torch.zeros(n, dtype=x.dtype).scatter_add_(0, dst, torch.ones(dst.numel(), dtype=x.dtype))
+    dis = deg.pow(-0.5)
+    dis[torch.isinf(dis)] = 0
+    norm = dis[src] * dis[dst]
+    out = torch.zeros_like(xw).index_add_(0, dst, norm.unsqueeze(1) * xw[src])
+    return out + bias
+
+
+def scatter_mean(src, index, n):
+    out = torch.zeros(n, src.size(1), dtype=src.dtype)
+    out.scatter_add_(0, index.unsqueeze(1).expand_as(src), src)
+    cnt = torch.bincount(index, minlength=n).to(src.dtype).clamp(min=1)
+    return out / cnt.unsqueeze(1)
+
+
+def sage_conv(x, edge_index, w_l, b_l, w_r):
+    m = scatter_mean(x[edge_index[0]], edge_index[1], x.size(0))
+    return m @ w_l.t() + b_l + x @ w_r.t()
+
+
+def graph_softmax(scores, batch):
+    if batch is None:
+        return torch.softmax(scores, dim=0)
+    g = int(batch.max()) + 1
+    peak = torch.full((g, 1), float("-inf")).index_reduce(0, batch, scores, "amax", include_self=True)
+    ex = torch.exp(scores - peak[batch])
+    tot = torch.zeros_like(peak).index_add_(0, batch, ex)
+    return ex / (tot[batch] + 1e-12)
+
+
+@torch.no_grad()
+def resgcn_forward(sd, n_layers, x, edge_index, edge_attr, batch=None):
+    """sd: state_dict of float32 CPU tensors with the reference keys."""
+    n = x.size(0)
+    d = sd["input_proj.0.weight"].size(0)
+    c = sd["edge_ctx.encode.0.weight"].size(0)
+    xn = F.batch_norm(x, sd["in_norm.norm.running_mean"], sd["in_norm.norm.running_var"],
+                      sd["in_norm.norm.weight"], sd["in_norm.norm.bias"], False, 0.0, 1e-5)
+    h = F.gelu(F.layer_norm(F.linear(xn, sd["input_proj.0.weight"], sd["input_proj.0.bias"]), (d,),
+                            sd["input_proj.1.weight"], sd["input_proj.1.bias"]))
+    prior = x[:, -3:]
+    pb = torch.sigmoid(F.linear(F.gelu(F.linear(prior, sd["prior_booster.0.weight"], sd["prior_booster.0.bias"])),
+                                sd["prior_booster.2.weight"], sd["prior_booster.2.bias"]))
+    h = h * (1.0 + pb)
+    enc = F.linear(F.gelu(F.linear(edge_attr, sd["edge_ctx.encode.0.weight"], sd["edge_ctx.encode.0.bias"])),
+                   sd["edge_ctx.encode.2.weight"], sd["edge_ctx.encode.2.bias"])
+    ctx = scatter_mean(enc, edge_index[1], n)
+    gate = torch.sigmoid(F.linear(F.layer_norm(ctx, (c,), sd["edge_ctx.to_gate.0.weight"], sd["edge_ctx.to_gate.0.bias"]),
+                                  sd["edge_ctx.to_gate.1.weight"], sd["edge_ctx.to_gate.1.bias"]))
+    states = [h]
+    for i in range(n_layers):
+        hn = F.layer_norm(h, (d,), sd[f"norms.{i}.weight"], sd[f"norms.{i}.bias"])
+        h_res = gcn_conv(hn, edge_index, sd[f"gcn_layers.{i}.lin.weight"], sd[f"gcn_layers.{i}.bias"])
+        h = h + F.gelu(h_res * gate)
+        states.append(h)
+    s = sage_conv(h, edge_index, sd["sage.lin_l.weight"], sd["sage.lin_l.bias"], sd["sage.lin_r.weight"])
+    states.append(F.gelu(F.layer_norm(s, (d,), sd["sage_norm.weight"], sd["sage_norm.bias"])))
+    w = torch.softmax(sd["jk_logits"], dim=0)
+    h_jk = torch.stack(states, 0).mul(w[:, None, None]).sum(0)
+    a = graph_softmax(F.linear(h_jk, sd["ctx.attn.weight"], sd["ctx.attn.bias"]), batch)
+    if batch is None:
+        g = (a * h_jk).sum(0, keepdim=True)
+    else:
+        ng = int(batch.max()) + 1
+        g = torch.zeros(ng, d).index_add_(0, batch, a * h_jk)[batch]
+    g = torch.sigmoid(F.linear(F.relu(F.linear(g, sd["ctx.compress.weight"], sd["ctx.compress.bias"])),
+                               sd["ctx.expand.weight"], sd["ctx.expand.bias"]))
+    z = h_jk * g
+    f = F.gelu(F.linear(F.layer_norm(z, (d,), sd["fuse.0.weight"], sd["fuse.0.bias"]),
+                        sd["fuse.1.weight"], sd["fuse.1.bias"]))
+    return F.linear(f, sd["head.weight"], sd["head.bias"])
