@@ -73,9 +73,34 @@ int ggc_ctx_destroy(ggc_ctx* ctx) {
     if (!ctx) return GGC_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    for (auto& r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& e : ctx->prof_pool) (void)hipEventDestroy(e);
     for (auto& b : ctx->slots) if (b.p) (void)hipFree(b.p);
     for (auto& kv : ctx->model.dev) if (kv.second.p) (void)hipFree(kv.second.p);
     delete ctx;
+    return GGC_OK;
+}
+
+int ggc_profile_enable(ggc_ctx* ctx, int on) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& r : ctx->prof) { ctx->prof_pool.push_back(r.a); ctx->prof_pool.push_back(r.b); }
+    ctx->prof.clear();
+    ctx->prof_on = on != 0;
+    return GGC_OK;
+}
+
+int ggc_profile_query(ggc_ctx* ctx, const char* kernel, int* launches, double* total_ms) {
+    if (!ctx || !kernel || !launches || !total_ms) return GGC_E_INVALID_ARG;
+    *launches = 0; *total_ms = 0.0;
+    for (auto& r : ctx->prof) {
+        if (std::strcmp(r.name, kernel) != 0) continue;
+        GGC_HIP(ctx, hipEventSynchronize(r.b));
+        float ms = 0.0f;
+        GGC_HIP(ctx, hipEventElapsedTime(&ms, r.a, r.b));
+        *total_ms += ms; *launches += 1;
+    }
     return GGC_OK;
 }
 

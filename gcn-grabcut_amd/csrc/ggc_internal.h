@@ -54,9 +54,18 @@ struct GraphState {
 
 } // namespace ggc
 
+namespace ggc {
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's
+// roofline leg): off by default, costs two event records per profiled launch.
+struct ProfRec { const char* name; hipEvent_t a, b; };
+} // namespace ggc
+
 struct ggc_ctx {
     int device = 0;
     std::string err;
+    bool prof_on = false;
+    std::vector<ggc::ProfRec> prof;        // recorded scopes since ggc_profile_enable
+    std::vector<hipEvent_t> prof_pool;     // recycled events
     ggc::Buf slots[ggc::S_COUNT];
     ggc::ResgcnWeights model;
     ggc::GraphState graph;
@@ -96,6 +105,22 @@ inline T* scratch_t(ggc_ctx* ctx, int slot, size_t count) {
 }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+struct ProfScope {
+    ggc_ctx* ctx; hipStream_t st; hipEvent_t b = nullptr;
+    ProfScope(ggc_ctx* c, hipStream_t s, const char* name) : ctx(c), st(s) {
+        if (!c->prof_on) return;
+        hipEvent_t ev[2];
+        for (int i = 0; i < 2; ++i) {
+            if (!c->prof_pool.empty()) { ev[i] = c->prof_pool.back(); c->prof_pool.pop_back(); }
+            else if (hipEventCreate(&ev[i]) != hipSuccess) return;
+        }
+        (void)hipEventRecord(ev[0], s);
+        b = ev[1];
+        c->prof.push_back({name, ev[0], ev[1]});
+    }
+    ~ProfScope() { if (b) (void)hipEventRecord(b, st); }
+};
 
 // ---- device helpers -------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

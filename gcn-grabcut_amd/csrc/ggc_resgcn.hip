@@ -708,6 +708,7 @@ static int launch_gemm(ggc_ctx* ctx, hipStream_t st, int N, const GemmArgs& a) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    ProfScope prof(ctx, st, MODE == 0 ? "gcn_gemm" : MODE == 1 ? "sage_gemm" : "head_gemm");
     hipLaunchKernelGGL((k_gemm<D, MODE>), dim3(cdiv(N, 128)), dim3(256), lds, st, N, a);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
@@ -717,6 +718,7 @@ template <int D, int MODE>
 static int launch_aggregate(ggc_ctx* ctx, hipStream_t st, int N, const float* xw, const int32_t* row_ptr,
                             const int32_t* col, const float* dis, const float* bias, const float* gate,
                             const float* h, float* out) {
+    ProfScope prof(ctx, st, MODE == 0 ? "gcn_aggregate" : "sage_aggregate");
     hipLaunchKernelGGL((k_aggregate<D, MODE>), dim3(cdiv(N, AggCfg<D>::RPB)), dim3(256), 0, st,
                        N, xw, row_ptr, col, dis, bias, gate, h, out);
     GGC_LAUNCH_CHECK(ctx);

@@ -30,6 +30,8 @@ SIGNATURES = {
     "ggc_ctx_create": [_i, C.POINTER(_vp)],
     "ggc_ctx_destroy": [_vp],
     "ggc_last_error": [_vp],
+    "ggc_profile_enable": [_vp, _i],
+    "ggc_profile_query": [_vp, C.c_char_p, C.POINTER(_i), C.POINTER(C.c_double)],
     "ggc_preprocess": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ggc_slic": [_vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _i, _vp, _vp],
     "ggc_graph_count": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
@@ -129,6 +131,15 @@ class Context:
 
     def call(self, name: str, *args) -> None:
         self.check(getattr(self.lib, name)(self.handle, *args))
+
+    def profile_enable(self, on: bool = True) -> None:
+        self.call("ggc_profile_enable", int(on))
+
+    def profile_query(self, kernel: str) -> tuple[int, float]:
+        """(launches, total milliseconds) of one profiled kernel since profile_enable."""
+        n, ms = C.c_int(0), C.c_double(0.0)
+        self.call("ggc_profile_query", kernel.encode(), C.byref(n), C.byref(ms))
+        return n.value, ms.value
 
 
 _contexts: dict[int, Context] = {}

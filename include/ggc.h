@@ -62,6 +62,14 @@ int         ggc_ctx_create(int device_id, ggc_ctx** out);
 int         ggc_ctx_destroy(ggc_ctx* ctx);
 const char* ggc_last_error(const ggc_ctx* ctx); /* ctx may be NULL: last create error */
 
+/* Per-kernel timing for the roofline report (bench.py): while enabled, the
+ * dominant kernels are bracketed by HIP events on their launch stream.
+ * ggc_profile_enable(ctx, 1) clears earlier records and SYNCHRONISES the device;
+ * ggc_profile_query sums the recorded durations of one kernel by name
+ * ("gcn_aggregate", "gcn_gemm", "slic_assign", "maxflow", ...) and waits for them. */
+int ggc_profile_enable(ggc_ctx* ctx, int on);
+int ggc_profile_query(ggc_ctx* ctx, const char* kernel, int* launches, double* total_ms);
+
 /* --------------------------------------------------------------- G0 colour prep
  * Replaces GraphBuilder.__init__ (graph_builder.py:142-154): BGR->Lab (f64
  * arithmetic, stored f32), BGR->HSV (f64 -> f32), BGR->GRAY (8-bit fixed

@@ -104,14 +104,16 @@ def test_aggregate_bit_exact_and_fused(oracle, gpu_ctx, d):
     order = np.argsort(ei[1], kind="stable")
     assert (col.cpu().numpy() == ei[0][order]).all()
     xw_d, out = t(xw), torch.empty(n, d, device=dev)
+    bias_d, gate_d, h_d = t(bias), t(gate), t(h)      # keep alive across the async launches
     gpu_ctx.call("ggc_gcn_aggregate", st, n, d, xw_d.data_ptr(), row_ptr.data_ptr(), col.data_ptr(), dis.data_ptr(),
-                 t(bias).data_ptr(), None, None, out.data_ptr())
+                 bias_d.data_ptr(), None, None, out.data_ptr())
     want = oracle.gcn_aggregate(xw, ei, bias)
     assert np.array_equal(out.cpu().numpy(), want)
     gpu_ctx.call("ggc_gcn_aggregate", st, n, d, xw_d.data_ptr(), row_ptr.data_ptr(), col.data_ptr(), dis.data_ptr(),
-                 t(bias).data_ptr(), t(gate).data_ptr(), t(h).data_ptr(), out.data_ptr())
+                 bias_d.data_ptr(), gate_d.data_ptr(), h_d.data_ptr(), out.data_ptr())
     want = oracle.gcn_aggregate(xw, ei, bias, gate, h)
-    assert np.abs(out.cpu().numpy() - want).max() <= 2e-6
+    err = float(np.abs(out.cpu().numpy() - want).max())
+    assert err <= 2e-6, err
 
 
 def test_errors_are_loud(gpu_ctx):
