@@ -45,6 +45,7 @@ void ggo_preprocess(int H, int W, const uint8_t* bgr,
 /* individual steps, exposed for pinning against skimage/scipy */
 void ggo_slic_rescale_lab(int H, int W, const float* image, int rescale_input, float* out);
 void ggo_gaussian_f32(int H, int W, int C, const float* in, double sigma, float* out);
+int  ggo_gaussian_weights(double sigma, double* w /*[2r+1]*/, int cap); /* returns radius */
 int  ggo_slic_grid(int H, int W, int n_segments, int* step_y, int* step_x,
                    int* start_y, int* start_x, int* ny, int* nx);
 /* centers: [K,5] = y,x,c0,c1,c2 in/out; labels out; image already scaled by 1/compactness */

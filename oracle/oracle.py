@@ -105,3 +105,74 @@ def gcn_conv(x, edge_index, W, bias):
     out = np.empty_like(x)
     L.ggo_gcn_conv(_i(n), _i(ei.shape[1]), _i(d), _p(x), _p(ei), _p(f32(W)), _p(f32(bias)), _p(out))
     return out
+
+
+# ---------------------------------------------------------------- G0 / G1
+
+def preprocess(bgr):
+    """-> lab, hsv (H,W,3) f32, gray, grad (H,W) f32."""
+    L = lib()
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w = bgr.shape[:2]
+    lab = np.empty((h, w, 3), np.float32)
+    hsv = np.empty((h, w, 3), np.float32)
+    gray = np.empty((h, w), np.float32)
+    grad = np.empty((h, w), np.float32)
+    L.ggo_preprocess(_i(h), _i(w), _p(bgr), _p(lab), _p(hsv), _p(gray), _p(grad))
+    return lab, hsv, gray, grad
+
+
+def slic_rescale_lab(image, rescale_input=True):
+    L = lib()
+    image = f32(image)
+    h, w = image.shape[:2]
+    out = np.empty_like(image)
+    L.ggo_slic_rescale_lab(_i(h), _i(w), _p(image), _i(int(rescale_input)), _p(out))
+    return out
+
+
+def gaussian(image, sigma=1.0):
+    L = lib()
+    image = f32(image)
+    h, w, c = image.shape
+    out = np.empty_like(image)
+    L.ggo_gaussian_f32(_i(h), _i(w), _i(c), _p(image), _d(sigma), _p(out))
+    return out
+
+
+def slic_grid(h, w, n_segments):
+    L = lib()
+    v = [C.c_int() for _ in range(6)]
+    k = L.ggo_slic_grid(_i(h), _i(w), _i(n_segments), *[C.byref(x) for x in v])
+    sy, sx, y0, x0, ny, nx = [x.value for x in v]
+    return dict(K=k, step_y=sy, step_x=sx, start_y=y0, start_x=x0, ny=ny, nx=nx)
+
+
+def slic_kmeans(image, seeds_yx, step, max_iter=10):
+    L = lib()
+    image = f32(image)
+    h, w = image.shape[:2]
+    k = seeds_yx.shape[0]
+    centers = np.zeros((k, 5), np.float32)
+    centers[:, :2] = seeds_yx
+    labels = np.empty((h, w), np.int32)
+    L.ggo_slic_kmeans(_i(h), _i(w), _p(image), _i(k), _p(centers), _f(step), _i(max_iter), _p(labels))
+    return labels, centers
+
+
+def slic_connectivity(labels, min_size, max_size):
+    L = lib()
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    h, w = labels.shape
+    out = np.empty_like(labels)
+    n = L.ggo_slic_connectivity(_i(h), _i(w), _p(labels), _i(int(min_size)), _i(int(max_size)), _p(out))
+    return out, n
+
+
+def slic(image, n_segments, compactness=10.0, sigma=1.0, rescale_input=True):
+    L = lib()
+    image = f32(image)
+    h, w = image.shape[:2]
+    seg = np.empty((h, w), np.int32)
+    n = L.ggo_slic(_i(h), _i(w), _p(image), _i(n_segments), _f(compactness), _f(sigma), _i(int(rescale_input)), _p(seg))
+    return seg, n
