@@ -1,0 +1,450 @@
+// ggc_slic.hip — G1: skimage.segmentation.slic as the reference calls it
+// (graph_builder.py:177-188; semantics: SURVEY.md Appendix A.1).
+//
+// Pipeline per batch (all images H x W, one launch per step):
+//   k_minmax        global min / max of the Lab input (skimage >= 0.19 rescale)
+//   k_lab2          rescale to [0,1] and the second rgb2lab, float32
+//   k_gauss<axis>   separable Gaussian, f64 accumulation, y then x, * 1/compactness
+//   k_init_centers  regular-grid seeds, colour part 0
+//   10 x { k_slic_assign, k_slic_update }
+//   k_connectivity  skimage's raster-order connectivity enforcement
+//
+// Bit-exactness with the CPU path (integer label map) dictates the structure:
+//  * assignment is pixel-centric (no atomics): a 32x8 pixel tile gathers, in
+//    ascending cluster order, the clusters whose search window meets the tile
+//    (wave ballot + prefix compaction into LDS) and every pixel scans that list
+//    with a strict '>' — identical to the sequential "lowest k wins ties";
+//  * the centroid update is one lane per cluster walking its own window in
+//    raster order with float32 running sums — identical rounding to skimage;
+//  * all arithmetic is compiled without FMA contraction.
+#include "ggc_internal.h"
+#include "ggc_math.h"
+#include <cmath>
+#include <vector>
+
+namespace ggc {
+
+// ---------------------------------------------------------------- min / max
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+__global__ void k_minmax_init(int B, uint32_t* mm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { mm[2 * i] = 0xFFFFFFFFu; mm[2 * i + 1] = 0u; }
+}
+
+__global__ void __launch_bounds__(256) k_minmax(size_t n, const float* __restrict__ img, uint32_t* mm) {
+    const float* im = img + (size_t)blockIdx.y * n;
+    float lo = INFINITY, hi = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = im[i];
+        lo = fminf(lo, v); hi = fmaxf(hi, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[2 * blockIdx.y], f2ord(lo));
+        atomicMax(&mm[2 * blockIdx.y + 1], f2ord(hi));
+    }
+}
+
+// ------------------------------------------------ rescale + second rgb2lab (f32)
+__global__ void __launch_bounds__(256) k_lab2(size_t P, const float* __restrict__ img,
+                                              const uint32_t* __restrict__ mm, int rescale,
+                                              float* __restrict__ out) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const size_t base = ((size_t)blockIdx.y * P + p) * 3;
+    const float mn = ord2f(mm[2 * blockIdx.y]), mx = ord2f(mm[2 * blockIdx.y + 1]);
+    const float range = mx - mn;
+    float lin[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = img[base + c];
+        if (rescale) { v = v - mn; if (mx != mn) v = v / range; }
+        lin[c] = v > (float)0.04045 ? (float)det_pow24((double)((v + (float)0.055) / (float)1.055))
+                                    : v / (float)12.92;
+    }
+    const float X = (lin[0] * (float)0.412453 + lin[1] * (float)0.357580) + lin[2] * (float)0.180423;
+    const float Y = (lin[0] * (float)0.212671 + lin[1] * (float)0.715160) + lin[2] * (float)0.072169;
+    const float Z = (lin[0] * (float)0.019334 + lin[1] * (float)0.119193) + lin[2] * (float)0.950227;
+    const float t[3] = {X / (float)0.95047, Y / 1.0f, Z / (float)1.08883};
+    float f[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        f[c] = t[c] > (float)0.008856 ? (float)det_cbrt((double)t[c]) : (float)7.787 * t[c] + (float)(16.0 / 116.0);
+    out[base + 0] = 116.0f * f[1] - 16.0f;
+    out[base + 1] = 500.0f * (f[0] - f[1]);
+    out[base + 2] = 200.0f * (f[1] - f[2]);
+}
+
+// ----------------------------------------------------------------- Gaussian
+constexpr int MAX_RADIUS = 16;
+struct GaussW { double w[2 * MAX_RADIUS + 1]; int r; };
+
+__device__ __forceinline__ int reflect_sym(int i, int n) { // scipy 'reflect': (b a | a b c | c b)
+    if (n == 1) return 0;
+    const int period = 2 * n;
+    i %= period; if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+// One thread per (pixel, channel).  Same op order as scipy's correlate1d for a
+// symmetric kernel: centre tap first, then pairs from the outermost inwards.
+template <int AXIS>
+__global__ void __launch_bounds__(256) k_gauss(int H, int W, const float* __restrict__ in, GaussW g,
+                                               float scale, int apply_scale, float* __restrict__ out) {
+    const size_t n = (size_t)H * W * 3;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* im = in + (size_t)blockIdx.y * n;
+    const int c = (int)(i % 3);
+    const int x = (int)((i / 3) % W);
+    const int y = (int)(i / ((size_t)3 * W));
+    const int l = AXIS == 0 ? y : x;
+    const int len = AXIS == 0 ? H : W;
+    auto at = [&](int idx) -> double {
+        const int j = reflect_sym(idx, len);
+        return (double)(AXIS == 0 ? im[((size_t)j * W + x) * 3 + c] : im[((size_t)y * W + j) * 3 + c]);
+    };
+    double tmp = at(l) * g.w[g.r];
+    for (int jj = -g.r; jj < 0; ++jj) tmp += (at(l + jj) + at(l - jj)) * g.w[jj + g.r];
+    float v = (float)tmp;
+    if (apply_scale) v = v * scale;
+    out[(size_t)blockIdx.y * n + i] = v;
+}
+
+__global__ void __launch_bounds__(256) k_scale(size_t n, const float* __restrict__ in, float scale,
+                                               float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * scale;
+}
+
+// ------------------------------------------------------------------ k-means
+struct SlicGeom {
+    int H, W, K;
+    int ny, nx, start_y, start_x, step_y, step_x;  // seed grid
+    int win_y, win_x;                               // window half-steps from the ACTUAL seed count
+    float sw;                                       // spatial weight 1 / step^2
+};
+
+// search window of a centre, exactly as _slic_cython truncates it
+__device__ __forceinline__ int4 slic_window(float cy, float cx, const SlicGeom& g) {
+    if (cy != cy || cx != cx) return make_int4(0, 0, 0, 0);   // dead seed (0/0): never matches again
+    float fy0 = cy - (float)(2 * g.win_y); if (!(fy0 > 0.0f)) fy0 = 0.0f;
+    float fy1 = cy + (float)(2 * g.win_y) + 1.0f; if (!(fy1 < (float)g.H)) fy1 = (float)g.H;
+    float fx0 = cx - (float)(2 * g.win_x); if (!(fx0 > 0.0f)) fx0 = 0.0f;
+    float fx1 = cx + (float)(2 * g.win_x) + 1.0f; if (!(fx1 < (float)g.W)) fx1 = (float)g.W;
+    return make_int4((int)fy0, (int)fy1, (int)fx0, (int)fx1);  // y0, y1, x0, x1
+}
+
+__global__ void k_init_centers(SlicGeom g, float* __restrict__ centers, int4* __restrict__ bounds) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= g.K) return;
+    const size_t o = (size_t)blockIdx.y * g.K + k;
+    const float cy = (float)(g.start_y + (k / g.nx) * g.step_y);
+    const float cx = (float)(g.start_x + (k % g.nx) * g.step_x);
+    centers[o * 5 + 0] = cy; centers[o * 5 + 1] = cx;
+    centers[o * 5 + 2] = 0.0f; centers[o * 5 + 3] = 0.0f; centers[o * 5 + 4] = 0.0f;
+    bounds[o] = slic_window(cy, cx, g);
+}
+
+struct Cand { int k, y0, y1, x0, x1; float cy, cx, c0, c1, c2; };
+
+constexpr int TILE_W = 32, TILE_H = 8;
+
+__global__ void __launch_bounds__(256) k_slic_assign(SlicGeom g, const float* __restrict__ image,
+                                                     const float* __restrict__ centers,
+                                                     const int4* __restrict__ bounds,
+                                                     int32_t* __restrict__ labels, int32_t* __restrict__ stale) {
+    __shared__ Cand cand[256];
+    __shared__ int wcount[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int tx0 = blockIdx.x * TILE_W, ty0 = blockIdx.y * TILE_H;
+    const int px = tx0 + (tid & 31), py = ty0 + (tid >> 5);
+    const bool inb = px < g.W && py < g.H;
+    const size_t P = (size_t)g.H * g.W;
+    const size_t p = (size_t)b * P + (size_t)py * g.W + px;
+    float i0 = 0.f, i1 = 0.f, i2 = 0.f;
+    if (inb) { i0 = image[3 * p]; i1 = image[3 * p + 1]; i2 = image[3 * p + 2]; }
+    const float fy = (float)py, fx = (float)px;
+    float best = INFINITY;
+    int lab = -1;
+    const float* cen = centers + (size_t)b * g.K * 5;
+    const int4* bnd = bounds + (size_t)b * g.K;
+    for (int base = 0; base < g.K; base += 256) {
+        const int k = base + tid;
+        bool hit = false;
+        int4 bd = make_int4(0, 0, 0, 0);
+        if (k < g.K) {
+            bd = bnd[k];
+            hit = bd.x < ty0 + TILE_H && bd.y > ty0 && bd.z < tx0 + TILE_W && bd.w > tx0 && bd.y > bd.x && bd.w > bd.z;
+        }
+        const unsigned long long bal = __ballot(hit);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wave) off += wcount[w]; total += wcount[w]; }
+        if (hit) {
+            Cand c;
+            c.k = k; c.y0 = bd.x; c.y1 = bd.y; c.x0 = bd.z; c.x1 = bd.w;
+            c.cy = cen[k * 5 + 0]; c.cx = cen[k * 5 + 1];
+            c.c0 = cen[k * 5 + 2]; c.c1 = cen[k * 5 + 3]; c.c2 = cen[k * 5 + 4];
+            cand[off + pre] = c;
+        }
+        __syncthreads();
+        if (inb) {
+            for (int i = 0; i < total; ++i) {
+                const Cand& c = cand[i];
+                if (py >= c.y0 && py < c.y1 && px >= c.x0 && px < c.x1) {
+                    const float ty = c.cy - fy, tx = c.cx - fx;
+                    float d = (ty * ty + tx * tx) * g.sw;
+                    float dc = 0.0f, t;
+                    t = i0 - c.c0; dc += t * t;
+                    t = i1 - c.c1; dc += t * t;
+                    t = i2 - c.c2; dc += t * t;
+                    d += dc;
+                    if (best > d) { best = d; lab = c.k; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (inb) {
+        if (lab >= 0) labels[p] = lab;
+        else atomicOr(&stale[b], 1);   // no window covers the pixel: it keeps its previous label
+    }
+}
+
+// One lane per cluster: float32 running sums over its pixels in raster order.
+__global__ void __launch_bounds__(64) k_slic_update(SlicGeom g, const float* __restrict__ image,
+                                                    const int32_t* __restrict__ labels,
+                                                    const int32_t* __restrict__ stale,
+                                                    float* __restrict__ centers, int4* __restrict__ bounds) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= g.K) return;
+    const int b = blockIdx.y;
+    const size_t o = (size_t)b * g.K + k;
+    int4 bd = bounds[o];
+    if (stale[b]) bd = make_int4(0, g.H, 0, g.W);   // some pixel kept an old label: scan everything
+    const size_t P = (size_t)g.H * g.W;
+    const int32_t* lb = labels + (size_t)b * P;
+    const float* im = image + (size_t)b * P * 3;
+    float sy = 0.f, sx = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    int cnt = 0;
+    for (int y = bd.x; y < bd.y; ++y) {
+        const size_t row = (size_t)y * g.W;
+        for (int x = bd.z; x < bd.w; ++x) {
+            if (lb[row + x] == k) {
+                const float* px = im + (row + x) * 3;
+                cnt += 1;
+                sy += (float)y; sx += (float)x;
+                s0 += px[0]; s1 += px[1]; s2 += px[2];
+            }
+        }
+    }
+    const float n = (float)cnt;
+    const float cy = sy / n, cx = sx / n;
+    centers[o * 5 + 0] = cy; centers[o * 5 + 1] = cx;
+    centers[o * 5 + 2] = s0 / n; centers[o * 5 + 3] = s1 / n; centers[o * 5 + 4] = s2 / n;
+    bounds[o] = slic_window(cy, cx, g);
+}
+
+// ------------------------------------------------ connectivity enforcement
+// skimage's _enforce_label_connectivity_cython is defined by a raster scan whose
+// relabelling depends on visit order (SURVEY hard part 1.iii).  This version
+// replays it literally, one thread per image (images of a batch in parallel).
+__global__ void __launch_bounds__(64) k_connectivity_seq(int H, int W, const int32_t* __restrict__ labels,
+                                                         int min_size, int max_size,
+                                                         int32_t* __restrict__ queue,
+                                                         int32_t* __restrict__ out, int32_t* __restrict__ n_nodes) {
+    if (threadIdx.x != 0) return;
+    const int b = blockIdx.x;
+    const size_t P = (size_t)H * W;
+    const int32_t* lb = labels + (size_t)b * P;
+    int32_t* o = out + (size_t)b * P;
+    int32_t* q = queue + (size_t)b * (size_t)(max_size > 0 ? max_size : 1);
+    int cur = 0;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int p0 = y * W + x;
+            if (o[p0] >= 0) continue;
+            int adjacent = 0;
+            const int label = lb[p0];
+            o[p0] = cur;
+            int size = 1, visited = 0;
+            q[0] = p0;
+            while (visited < size && size < max_size) {
+                const int pc = q[visited];
+                const int yc = pc / W, xc = pc - yc * W;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int xx = xc + (i == 0 ? 1 : i == 1 ? -1 : 0);
+                    const int yy = yc + (i == 2 ? 1 : i == 3 ? -1 : 0);
+                    if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                    const int pp = yy * W + xx;
+                    const int op = o[pp];
+                    if (op == -1 && lb[pp] == label) {
+                        o[pp] = cur;
+                        q[size] = pp;
+                        size += 1;
+                        if (size >= max_size) break;
+                    } else if (op >= 0 && op != cur) {
+                        adjacent = op;
+                    }
+                }
+                visited += 1;
+            }
+            if (size < min_size) {
+                for (int i = 0; i < size; ++i) o[q[i]] = adjacent;
+            } else {
+                cur += 1;
+            }
+        }
+    n_nodes[b] = cur > 0 ? cur : 1;
+}
+
+// ------------------------------------------------------------- host helpers
+
+// numpy's pairwise summation for n <= 128 (scipy normalises the kernel with ndarray.sum())
+static double np_pairwise_sum(const double* a, int n) {
+    if (n < 8) { double s = 0.0; for (int i = 0; i < n; ++i) s += a[i]; return s; }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+// skimage.util.regular_grid((1, H, W), n) (util/_regular_grid.py:61-83)
+struct Grid { int step_y, step_x, start_y, start_x, ny, nx, K; };
+static Grid regular_grid(int H, int W, int n_points) {
+    Grid g{};
+    const double dims[3] = {1.0, (double)(H <= W ? H : W), (double)(H <= W ? W : H)};
+    const double space = 1.0 * H * W;
+    if (space <= (double)n_points) { g = {1, 1, 0, 0, H, W, H * W}; return g; }
+    double st[3];
+    for (int i = 0; i < 3; ++i) st[i] = std::pow(space / n_points, 1.0 / 3.0);
+    if (dims[0] < st[0] || dims[1] < st[1] || dims[2] < st[2]) {
+        for (int dim = 0; dim < 3; ++dim) {
+            st[dim] = dims[dim];
+            double sp = 1.0;
+            for (int j = dim + 1; j < 3; ++j) sp *= dims[j];
+            for (int j = dim + 1; j < 3; ++j) st[j] = std::pow(sp / n_points, 1.0 / (3 - dim - 1));
+            if (dims[0] >= st[0] && dims[1] >= st[1] && dims[2] >= st[2]) break;
+        }
+    }
+    int starts[3], steps[3];
+    for (int i = 0; i < 3; ++i) { starts[i] = (int)std::floor(st[i] / 2.0); steps[i] = (int)std::rint(st[i]); }
+    const int iy = (H <= W) ? 1 : 2, ix = (H <= W) ? 2 : 1;
+    g.step_y = steps[iy]; g.start_y = starts[iy];
+    g.step_x = steps[ix]; g.start_x = starts[ix];
+    g.ny = std::max(0, (H - g.start_y + g.step_y - 1) / g.step_y);
+    g.nx = std::max(0, (W - g.start_x + g.step_x - 1) / g.step_x);
+    g.K = g.ny * g.nx;
+    return g;
+}
+
+} // namespace ggc
+
+using namespace ggc;
+
+extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, const float* image,
+                        int n_segments, float compactness, float sigma, int rescale_input,
+                        int32_t* segments, int32_t* n_nodes) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, B >= 1 && H >= 1 && W >= 1 && B <= 65535, GGC_E_SHAPE, "bad shape B=%d H=%d W=%d", B, H, W);
+    GGC_REQUIRE(ctx, image && segments && n_nodes, GGC_E_INVALID_ARG, "null pointer");
+    GGC_REQUIRE(ctx, n_segments >= 1 && compactness > 0.0f && sigma >= 0.0f, GGC_E_INVALID_ARG,
+                "bad SLIC parameters n_segments=%d compactness=%g sigma=%g", n_segments, compactness, sigma);
+    GGC_REQUIRE(ctx, (size_t)H * W < (1u << 30), GGC_E_SHAPE, "image too large");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t P = (size_t)H * W;
+
+    const Grid seed = regular_grid(H, W, n_segments);
+    GGC_REQUIRE(ctx, seed.K >= 1, GGC_E_SHAPE, "no SLIC seeds for %dx%d with n_segments=%d", H, W, n_segments);
+    const Grid win = regular_grid(H, W, seed.K);   // _slic_cython recomputes the grid from the seed count
+    SlicGeom g{};
+    g.H = H; g.W = W; g.K = seed.K;
+    g.ny = seed.ny; g.nx = seed.nx; g.start_y = seed.start_y; g.start_x = seed.start_x;
+    g.step_y = seed.step_y; g.step_x = seed.step_x;
+    g.win_y = win.step_y; g.win_x = win.step_x;
+    const float step = (float)std::max(std::max(seed.step_y, seed.step_x), 1);
+    g.sw = (float)(1.0 / (double)(step * step));
+
+    float* img_a = scratch_t<float>(ctx, S_SLIC_IMG, (size_t)B * P * 3);
+    float* img_b = scratch_t<float>(ctx, S_SLIC_TMP, (size_t)B * P * 3);
+    uint32_t* mm = scratch_t<uint32_t>(ctx, S_SLIC_MINMAX, (size_t)B * 2);
+    float* centers = scratch_t<float>(ctx, S_SLIC_CENTERS, (size_t)B * g.K * 5);
+    int4* bounds = scratch_t<int4>(ctx, S_SLIC_AUX, (size_t)B * g.K);
+    int32_t* raw = scratch_t<int32_t>(ctx, S_SLIC_LABELS, (size_t)B * P);
+    int32_t* stale = scratch_t<int32_t>(ctx, S_SLIC_AUX2, (size_t)B * 10);
+    if (!img_a || !img_b || !mm || !centers || !bounds || !raw || !stale) return GGC_E_OOM;
+
+    // 1-2: rescale + second Lab
+    hipLaunchKernelGGL(k_minmax_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, mm);
+    hipLaunchKernelGGL(k_minmax, dim3(std::min(cdiv(P * 3, 256 * 8), 256), B), dim3(256), 0, st, P * 3, image, mm);
+    hipLaunchKernelGGL(k_lab2, dim3(cdiv(P, 256), B), dim3(256), 0, st, P, image, mm, rescale_input, img_a);
+    GGC_LAUNCH_CHECK(ctx);
+    // 4-5: Gaussian (y then x) and the 1/compactness scale
+    const float ratio = (float)(1.0 / (double)compactness);
+    const float* km_img = nullptr;
+    if (sigma > 0.0f) {
+        GaussW gw{};
+        gw.r = (int)(4.0 * (double)sigma + 0.5);
+        GGC_REQUIRE(ctx, gw.r <= MAX_RADIUS, GGC_E_UNSUPPORTED, "sigma=%g needs radius %d > %d", sigma, gw.r, MAX_RADIUS);
+        const double s2 = (double)sigma * (double)sigma;
+        for (int i = -gw.r; i <= gw.r; ++i) gw.w[i + gw.r] = std::exp(-0.5 / s2 * (double)(i * i));
+        const double sum = np_pairwise_sum(gw.w, 2 * gw.r + 1);
+        for (int i = 0; i < 2 * gw.r + 1; ++i) gw.w[i] = gw.w[i] / sum;
+        const dim3 grid(cdiv(P * 3, 256), B);
+        hipLaunchKernelGGL((k_gauss<0>), grid, dim3(256), 0, st, H, W, img_a, gw, 1.0f, 0, img_b);
+        hipLaunchKernelGGL((k_gauss<1>), grid, dim3(256), 0, st, H, W, img_b, gw, ratio, 1, img_a);
+        km_img = img_a;
+    } else {
+        hipLaunchKernelGGL(k_scale, dim3(cdiv((size_t)B * P * 3, 256)), dim3(256), 0, st, (size_t)B * P * 3, img_a,
+                           ratio, img_b);
+        km_img = img_b;
+    }
+    GGC_LAUNCH_CHECK(ctx);
+    // 6: k-means, exactly 10 sweeps (the early exit of _slic_cython can never trigger)
+    hipLaunchKernelGGL(k_init_centers, dim3(cdiv(g.K, 256), B), dim3(256), 0, st, g, centers, bounds);
+    GGC_HIP(ctx, hipMemsetAsync(raw, 0, sizeof(int32_t) * (size_t)B * P, st));
+    GGC_HIP(ctx, hipMemsetAsync(stale, 0, sizeof(int32_t) * (size_t)B * 10, st));
+    for (int it = 0; it < 10; ++it) {
+        {
+            ProfScope prof(ctx, st, "slic_assign");
+            hipLaunchKernelGGL(k_slic_assign, dim3(cdiv(W, TILE_W), cdiv(H, TILE_H), B), dim3(256), 0, st, g, km_img,
+                               centers, bounds, raw, stale + (size_t)it * B);
+        }
+        {
+            ProfScope prof(ctx, st, "slic_update");
+            hipLaunchKernelGGL(k_slic_update, dim3(cdiv(g.K, 64), B), dim3(64), 0, st, g, km_img, raw,
+                               stale + (size_t)it * B, centers, bounds);
+        }
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    // 7: connectivity
+    const double seg_size = (double)P / (double)g.K;
+    const int min_size = (int)(0.5 * seg_size), max_size = (int)(3.0 * seg_size);
+    int32_t* queue = scratch_t<int32_t>(ctx, S_SLIC_AUX3, (size_t)B * (size_t)std::max(max_size, 1));
+    if (!queue) return GGC_E_OOM;
+    GGC_HIP(ctx, hipMemsetAsync(segments, 0xFF, sizeof(int32_t) * (size_t)B * P, st));
+    {
+        ProfScope prof(ctx, st, "slic_connectivity");
+        hipLaunchKernelGGL(k_connectivity_seq, dim3(B), dim3(64), 0, st, H, W, raw, min_size, max_size, queue, segments,
+                           n_nodes);
+    }
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}

@@ -32,6 +32,7 @@ SIGNATURES = {
     "ggc_last_error": [_vp],
     "ggc_profile_enable": [_vp, _i],
     "ggc_profile_query": [_vp, C.c_char_p, C.POINTER(_i), C.POINTER(C.c_double)],
+    "ggc_debug_read_scratch": [_vp, C.c_char_p, _vp, C.c_size_t],
     "ggc_preprocess": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ggc_slic": [_vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _i, _vp, _vp],
     "ggc_graph_count": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],

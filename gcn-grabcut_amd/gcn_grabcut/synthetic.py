@@ -45,7 +45,7 @@ def synthetic_image(height: int, width: int, seed: int, return_mask: bool = Fals
         img[inside] = (colour[None, :] * shade[inside][:, None])
         mask |= inside
     img += rng.integers(-10, 11, size=img.shape)
-    out = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    out = np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
     if return_mask:
         return out, mask.astype(np.uint8)
     return out
@@ -53,4 +53,5 @@ def synthetic_image(height: int, width: int, seed: int, return_mask: bool = Fals
 
 def synthetic_batch(n: int, height: int, width: int, config_id: int = 3, first_index: int = 0) -> np.ndarray:
     """(n, H, W, 3) uint8; image i uses seed 10_000 * config_id + first_index + i."""
-    return np.stack([synthetic_image(height, width, 10_000 * config_id + first_index + i) for i in range(n)])
+    return np.ascontiguousarray(
+        np.stack([synthetic_image(height, width, 10_000 * config_id + first_index + i) for i in range(n)]))

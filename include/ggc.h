@@ -25,6 +25,7 @@
 #ifndef GGC_H
 #define GGC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -69,6 +70,11 @@ const char* ggc_last_error(const ggc_ctx* ctx); /* ctx may be NULL: last create 
  * ("gcn_aggregate", "gcn_gemm", "slic_assign", "maxflow", ...) and waits for them. */
 int ggc_profile_enable(ggc_ctx* ctx, int on);
 int ggc_profile_query(ggc_ctx* ctx, const char* kernel, int* launches, double* total_ms);
+
+/* Diagnostic hook for the parity tests: copy the first `bytes` of a named
+ * scratch buffer ("slic_raw_labels", "slic_centers", "slic_image_a", ...) to
+ * host memory.  SYNCHRONISES the device. */
+int ggc_debug_read_scratch(ggc_ctx* ctx, const char* name, void* host_dst, size_t bytes);
 
 /* --------------------------------------------------------------- G0 colour prep
  * Replaces GraphBuilder.__init__ (graph_builder.py:142-154): BGR->Lab (f64
