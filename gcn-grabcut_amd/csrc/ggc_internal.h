@@ -49,6 +49,9 @@ struct GraphState {
     int B = 0, H = 0, W = 0;
     int64_t n_total = 0, e_total = 0;
     std::vector<int64_t> node_ptr, edge_ptr;
+    int64_t max_pairs = 0;                 // largest per-image undirected pair count
+    int n_max = 0;                         // row stride of the per-image scratch tables
+    const int32_t* n_nodes_dev = nullptr;  // caller's n_nodes[B] (must outlive ggc_graph_fill)
     bool valid = false;
 };
 

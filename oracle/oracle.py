@@ -176,3 +176,45 @@ def slic(image, n_segments, compactness=10.0, sigma=1.0, rescale_input=True):
     seg = np.empty((h, w), np.int32)
     n = L.ggo_slic(_i(h), _i(w), _p(image), _i(n_segments), _f(compactness), _f(sigma), _i(int(rescale_input)), _p(seg))
     return seg, n
+
+
+# ---------------------------------------------------------------- G2-G8
+
+def find_boundaries_inner(seg):
+    L = lib()
+    seg = np.ascontiguousarray(seg, dtype=np.int32)
+    h, w = seg.shape
+    out = np.empty((h, w), np.uint8)
+    L.ggo_find_boundaries_inner(_i(h), _i(w), _p(seg), _p(out))
+    return out
+
+
+def graph_build(segments, lab, hsv, grad, connectivity=4, n_nonlocal=4):
+    """-> dict(node_features, prior, centroids, area_ratio, edge_index (2,E) i64, edge_attr (E,5))."""
+    L = lib()
+    seg = np.ascontiguousarray(segments, dtype=np.int32)
+    h, w = seg.shape
+    lab, hsv, grad = f32(lab), f32(hsv), f32(grad)
+    n, e = C.c_int(), C.c_int()
+    g = L.ggo_graph_build(_i(h), _i(w), _p(seg), _p(lab), _p(hsv), _p(grad), _i(connectivity), _i(n_nonlocal),
+                          C.byref(n), C.byref(e))
+    g = C.c_void_p(g)
+    n, e = n.value, e.value
+    out = dict(node_features=np.empty((n, 16), np.float32), prior=np.empty((n, 3), np.float32),
+               centroids=np.empty((n, 2), np.float32), area_ratio=np.empty(n, np.float32),
+               edge_index=np.empty((2, e), np.int64), edge_attr=np.empty((e, 5), np.float32))
+    L.ggo_graph_get(g, _p(out["node_features"]), _p(out["prior"]), _p(out["centroids"]), _p(out["area_ratio"]),
+                    _p(out["edge_index"]), _p(out["edge_attr"]))
+    L.ggo_graph_free(g)
+    out["n_nodes"], out["n_edges"] = n, e
+    return out
+
+
+def auto_prior(segments, lab):
+    L = lib()
+    seg = np.ascontiguousarray(segments, dtype=np.int32)
+    h, w = seg.shape
+    n = int(seg.max()) + 1
+    out = np.empty((n, 3), np.float32)
+    L.ggo_auto_prior(_i(h), _i(w), _p(seg), _p(f32(lab)), _i(n), _p(out))
+    return out
