@@ -44,7 +44,7 @@ SIGNATURES = {
     "ggc_gcn_aggregate": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ggc_build_csr": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ggc_refine_trimap": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _i, _vp],
-    "ggc_seed_from_prior": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp],
+    "ggc_seed_from_prior": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, C.c_double, _vp],
     "ggc_grabcut": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _vp],
     "ggc_clean_mask": [_vp, _vp, _i, _i, _i, _vp, _f, _i, _vp],
     "ggc_compose_outputs": [_vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp],

@@ -196,7 +196,7 @@ int ggc_refine_trimap(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
  *   prior [dev] f32 [N_total,3] (columns 16..18 of x, contiguous copy) */
 int ggc_seed_from_prior(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                         const float* prior, const int32_t* node_ptr,
-                        const int32_t* segments, float seed_frac, uint8_t* trimap);
+                        const int32_t* segments, double seed_frac, uint8_t* trimap);
 
 /* ------------------------------------------------------------ C0-C6 GrabCut
  * Replaces GrabCut.run_with_trimap / run_with_bbox / refine

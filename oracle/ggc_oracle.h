@@ -92,7 +92,7 @@ void ggo_refine_trimap(int H, int W, const float* probs, int n_probs, const int3
                        const uint8_t* bgr, float thr_fg, float thr_bg, int radius, float eps,
                        int edge_aware, uint8_t* trimap);
 void ggo_seed_from_prior(int H, int W, const float* prior, int n_nodes, const int32_t* segments,
-                         float seed_frac, uint8_t* trimap);
+                         double seed_frac, uint8_t* trimap);
 
 /* ---- C0-C6: grabcut.py:81-168 / cv2.grabCut ---- */
 int ggo_grabcut(int H, int W, const uint8_t* image, uint8_t* mask, const int32_t* rect,

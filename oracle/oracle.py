@@ -218,3 +218,45 @@ def auto_prior(segments, lab):
     out = np.empty((n, 3), np.float32)
     L.ggo_auto_prior(_i(h), _i(w), _p(seg), _p(f32(lab)), _i(n), _p(out))
     return out
+
+
+# ---------------------------------------------------------------- P0-P3, S0
+
+def box_blur(img, radius):
+    L = lib()
+    img = f32(img)
+    h, w = img.shape
+    out = np.empty_like(img)
+    L.ggo_box_blur(_i(h), _i(w), _p(img), _i(radius), _p(out))
+    return out
+
+
+def guided_filter(guide, src, radius=8, eps=1e-3):
+    L = lib()
+    guide, src = f32(guide), f32(src)
+    h, w = guide.shape
+    out = np.empty_like(guide)
+    L.ggo_guided_filter(_i(h), _i(w), _p(guide), _p(src), _i(radius), _f(eps), _p(out))
+    return out
+
+
+def refine_trimap(probs, segments, bgr, thr_fg=0.55, thr_bg=0.55, radius=8, eps=1e-3, edge_aware=True):
+    L = lib()
+    probs = f32(probs)
+    seg = np.ascontiguousarray(segments, dtype=np.int32)
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w = seg.shape
+    out = np.empty((h, w), np.uint8)
+    L.ggo_refine_trimap(_i(h), _i(w), _p(probs), _i(probs.shape[0]), _p(seg), _p(bgr), _f(thr_fg), _f(thr_bg),
+                        _i(radius), _f(eps), _i(int(edge_aware)), _p(out))
+    return out
+
+
+def seed_from_prior(trimap, prior, segments, seed_frac=0.1):
+    L = lib()
+    out = np.ascontiguousarray(trimap, dtype=np.uint8).copy()
+    prior = f32(prior)
+    seg = np.ascontiguousarray(segments, dtype=np.int32)
+    h, w = seg.shape
+    L.ggo_seed_from_prior(_i(h), _i(w), _p(prior), _i(prior.shape[0]), _p(seg), _d(seed_frac), _p(out))
+    return out
