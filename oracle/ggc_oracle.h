@@ -36,6 +36,8 @@ extern "C" {
 /* ---- shared deterministic math (restated independently in the HIP code) ---- */
 double ggo_cbrt(double a);        /* a > 0 */
 double ggo_pow24(double a);       /* a^2.4, a > 0 */
+double ggo_exp(double x);
+double ggo_log(double x);
 
 /* ---- G0: GraphBuilder.__init__ (graph_builder.py:142-154) ---- */
 void ggo_preprocess(int H, int W, const uint8_t* bgr,

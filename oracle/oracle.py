@@ -24,7 +24,7 @@ def lib() -> C.CDLL:
         if not path.exists():
             raise RuntimeError(f"{path} missing: run `make -C {_DIR}`")
         _lib = C.CDLL(str(path))
-        for name, res, args in (("ggo_cbrt", _d, [_d]), ("ggo_pow24", _d, [_d]), ("ggo_iou", _d, None),
+        for name, res, args in (("ggo_cbrt", _d, [_d]), ("ggo_pow24", _d, [_d]), ("ggo_exp", _d, [_d]), ("ggo_log", _d, [_d]), ("ggo_iou", _d, None),
                                 ("ggo_grid_maxflow", _i64, None), ("ggo_graph_build", _vp, None)):
             fn = getattr(_lib, name, None)
             if fn is None:
@@ -260,3 +260,61 @@ def seed_from_prior(trimap, prior, segments, seed_frac=0.1):
     h, w = seg.shape
     L.ggo_seed_from_prior(_i(h), _i(w), _p(prior), _i(prior.shape[0]), _p(seg), _d(seed_frac), _p(out))
     return out
+
+
+# ---------------------------------------------------------------- C0-C6, K0, O0, R0
+
+def grid_maxflow(tw, nw):
+    """tw (H,W) int32 source-minus-sink; nw (4,H,W) int32 [left, up-left, up, up-right].
+    -> (flow value, source_side (H,W) uint8)."""
+    L = lib()
+    tw = np.ascontiguousarray(tw, dtype=np.int32)
+    nw = np.ascontiguousarray(nw, dtype=np.int32)
+    h, w = tw.shape
+    side = np.empty((h, w), np.uint8)
+    L.ggo_grid_maxflow.argtypes = [_i, _i, _vp, _vp, _vp]
+    flow = L.ggo_grid_maxflow(_i(h), _i(w), _p(tw), _p(nw), _p(side))
+    return int(flow), side
+
+
+def grabcut(image, mask, n_iter=5, mode=0, rect=None, seed=0, bgd=None, fgd=None):
+    """-> (binary (H,W) u8, mask out, bgd_model, fgd_model, rc) ; rc 1 = degenerate trimap."""
+    L = lib()
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = image.shape[:2]
+    m = np.ascontiguousarray(mask, dtype=np.uint8).copy() if mask is not None else np.zeros((h, w), np.uint8)
+    r = None if rect is None else np.ascontiguousarray(rect, dtype=np.int32)
+    bgd = np.zeros(65) if bgd is None else np.ascontiguousarray(bgd, dtype=np.float64).copy().ravel()
+    fgd = np.zeros(65) if fgd is None else np.ascontiguousarray(fgd, dtype=np.float64).copy().ravel()
+    binary = np.empty((h, w), np.uint8)
+    rc = L.ggo_grabcut(_i(h), _i(w), _p(image), _p(m), _p(r), _p(bgd), _p(fgd), _i(n_iter), _i(mode), _u64(seed),
+                       _p(binary))
+    return binary, m, bgd, fgd, rc
+
+
+def clean_mask(mask, min_area_ratio=0.002, keep_largest=False):
+    L = lib()
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, w = mask.shape
+    out = np.empty_like(mask)
+    L.ggo_clean_mask(_i(h), _i(w), _p(mask), _f(min_area_ratio), _i(int(keep_largest)), _p(out))
+    return out
+
+
+def compose(bgr, binary, alpha=0.45, tint_bgr=(100, 220, 0)):
+    L = lib()
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    binary = np.ascontiguousarray(binary, dtype=np.uint8)
+    h, w = binary.shape
+    overlay = np.empty((h, w, 3), np.uint8)
+    rgba = np.empty((h, w, 4), np.uint8)
+    L.ggo_compose(_i(h), _i(w), _p(bgr), _p(binary), _f(alpha), _i(tint_bgr[0]), _i(tint_bgr[1]), _i(tint_bgr[2]),
+                  _p(overlay), _p(rgba))
+    return overlay, rgba
+
+
+def iou(pred, gt):
+    L = lib()
+    pred = np.ascontiguousarray(pred, dtype=np.uint8)
+    gt = np.ascontiguousarray(gt, dtype=np.uint8)
+    return float(L.ggo_iou(_i(pred.size), _p(pred), _p(gt)))
