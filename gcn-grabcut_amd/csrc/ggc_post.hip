@@ -1,0 +1,220 @@
+// ggc_post.hip — K0 mask clean-up, O0 output composition, R0 IoU.
+//
+// clean_mask (reference pipeline.py:189-227) needs 8-connected components with
+// areas: a lock-free union-find over the foreground pixels (roots = smallest
+// pixel index of a component, so numbering follows raster order like the CPU
+// path), areas by integer atomics at the roots, then one pass applying the
+// keep rule.  overlay_mask / crop_foreground: grabcut.py:180-195.
+// IoU: metrics.py:79-84.
+#include "ggc_internal.h"
+
+namespace ggc {
+
+struct PDims { int B, H, W, P; };
+
+__device__ __forceinline__ int uf_find(const int32_t* parent, int i) {
+    int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != i) { i = p; p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return i;
+}
+__device__ __forceinline__ void uf_union(int32_t* parent, int a, int b) {
+    for (;;) {
+        a = uf_find(parent, a); b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }      // link the larger root under the smaller
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cc_init(PDims d, const uint8_t* __restrict__ mask, int32_t* __restrict__ parent,
+                                                 int32_t* __restrict__ total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int on = 0, b = -1;
+    if (i < (size_t)d.B * d.P) {
+        on = mask[i] != 0;
+        b = (int)(i / d.P);
+        parent[i] = on ? (int)(i % d.P) : -1;
+    }
+    // total[b] != 0  <=>  the image has foreground (pipeline.py:208).  A wave can straddle images.
+    if (d.P >= 64) {
+        const int b0 = __builtin_amdgcn_readfirstlane(b);
+        const unsigned long long same = __ballot(on && b == b0), next = __ballot(on && b != b0);
+        if ((threadIdx.x & 63) == 0 && b0 >= 0) {
+            if (same) atomicOr(&total[b0], 1);
+            if (next) atomicOr(&total[b0 + 1], 1);
+        }
+    } else if (on) {
+        atomicOr(&total[b], 1);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cc_merge(PDims d, int32_t* __restrict__ parent) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= d.W || y >= d.H) return;
+    int32_t* par = parent + (size_t)blockIdx.z * d.P;
+    const int p = y * d.W + x;
+    if (par[p] < 0) return;
+    // 8-connectivity: link with the four already-scanned neighbours (left, up-left, up, up-right)
+    if (x > 0 && par[p - 1] >= 0) uf_union(par, p, p - 1);
+    if (y > 0) {
+        if (par[p - d.W] >= 0) uf_union(par, p, p - d.W);
+        if (x > 0 && par[p - d.W - 1] >= 0) uf_union(par, p, p - d.W - 1);
+        if (x + 1 < d.W && par[p - d.W + 1] >= 0) uf_union(par, p, p - d.W + 1);
+    }
+}
+
+// NB: a wave of a row-block may straddle two images only if P % 64 != 0; total[] is per image so guard by image.
+__global__ void __launch_bounds__(256) k_cc_area(PDims d, int32_t* __restrict__ parent, int32_t* __restrict__ area) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)d.B * d.P) return;
+    const size_t base = (i / d.P) * d.P;
+    const int p = (int)(i - base);
+    if (parent[i] < 0) return;
+    const int r = uf_find(parent + base, p);
+    parent[i] = r;                                          // compress (roots keep pointing at themselves)
+    atomicAdd(&area[base + r], 1);
+}
+
+// best[b] = max over components of (area << 32 | ~root): largest area, ties to the first component in raster order
+__global__ void __launch_bounds__(256) k_cc_best(PDims d, double min_area, const int32_t* __restrict__ parent,
+                                                 const int32_t* __restrict__ area, unsigned long long* __restrict__ best,
+                                                 int32_t* __restrict__ any) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)d.B * d.P) return;
+    const int b = (int)(i / d.P), p = (int)(i % d.P);
+    if (parent[i] != p) return;                              // roots only
+    const int a = area[i];
+    atomicMax(&best[b], ((unsigned long long)(unsigned)a << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p));
+    if ((double)a >= min_area) atomicOr(&any[b], 1);
+}
+
+__global__ void __launch_bounds__(256) k_cc_apply(PDims d, double min_area, int keep_largest, int passthrough,
+                                                  const uint8_t* __restrict__ mask, const int32_t* __restrict__ parent,
+                                                  const int32_t* __restrict__ area,
+                                                  const unsigned long long* __restrict__ best,
+                                                  const int32_t* __restrict__ any, const int32_t* __restrict__ total,
+                                                  uint8_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)d.B * d.P) return;
+    const int b = (int)(i / d.P);
+    if (passthrough || total[b] == 0) { out[i] = mask[i]; return; }   // pipeline.py:208-209
+    const int r = parent[i];
+    uint8_t keep = 0;
+    if (r >= 0) {
+        const size_t base = (size_t)b * d.P;
+        const int best_root = (int)(0xFFFFFFFFu - (unsigned)(best[b] & 0xFFFFFFFFull));
+        keep = (keep_largest || !any[b]) ? (r == best_root) : ((double)area[base + r] >= min_area);
+    }
+    out[i] = keep;
+}
+
+__global__ void __launch_bounds__(256) k_compose(size_t n, const uint8_t* __restrict__ bgr, const uint8_t* __restrict__ binary,
+                                                 float alpha, float tb, float tg, float tr, uint8_t* __restrict__ overlay,
+                                                 uint8_t* __restrict__ rgba) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float m = binary[i] ? 1.0f : 0.0f;
+    const float tint[3] = {tb, tg, tr};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint8_t v8 = bgr[3 * i + c];
+        if (overlay) {
+            float v = (float)v8 * (1.0f - alpha * m) + (tint[c] * alpha) * m;
+            v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+            overlay[3 * i + c] = (uint8_t)v;
+        }
+        if (rgba) rgba[4 * i + c] = v8;
+    }
+    if (rgba) rgba[4 * i + 3] = binary[i] ? 255 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_iou_count(PDims d, const uint8_t* __restrict__ pred, const uint8_t* __restrict__ gt,
+                                                   unsigned long long* __restrict__ cnt /*[B,3] tp fp fn*/) {
+    const int b = blockIdx.y;
+    unsigned int tp = 0, fp = 0, fn = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.P; p += gridDim.x * blockDim.x) {
+        const int a = pred[(size_t)b * d.P + p] != 0, g = gt[(size_t)b * d.P + p] != 0;
+        tp += a & g; fp += a & (1 - g); fn += (1 - a) & g;
+    }
+    for (int o = 32; o > 0; o >>= 1) { tp += __shfl_xor(tp, o, 64); fp += __shfl_xor(fp, o, 64); fn += __shfl_xor(fn, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&cnt[3 * b], (unsigned long long)tp); atomicAdd(&cnt[3 * b + 1], (unsigned long long)fp);
+        atomicAdd(&cnt[3 * b + 2], (unsigned long long)fn);
+    }
+}
+__global__ void k_iou_final(int B, const unsigned long long* __restrict__ cnt, double* __restrict__ iou) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double tp = (double)cnt[3 * b], fp = (double)cnt[3 * b + 1], fn = (double)cnt[3 * b + 2];
+    iou[b] = tp / ((tp + fp + fn) + 1e-8);
+}
+
+} // namespace ggc
+
+using namespace ggc;
+
+extern "C" int ggc_clean_mask(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, const uint8_t* mask_in,
+                              float min_area_ratio, int keep_largest, uint8_t* mask_out) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, B >= 1 && H >= 1 && W >= 1 && B <= 65535, GGC_E_SHAPE, "bad shape B=%d H=%d W=%d", B, H, W);
+    GGC_REQUIRE(ctx, mask_in && mask_out, GGC_E_INVALID_ARG, "null pointer");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const PDims d{B, H, W, H * W};
+    const size_t BP = (size_t)B * d.P;
+    int32_t* parent = scratch_t<int32_t>(ctx, S_CC_A, BP);
+    int32_t* area = scratch_t<int32_t>(ctx, S_CC_B, BP);
+    unsigned long long* best = scratch_t<unsigned long long>(ctx, S_CC_C, (size_t)B * 2);
+    if (!parent || !area || !best) return GGC_E_OOM;
+    int32_t* any = reinterpret_cast<int32_t*>(best + B);
+    int32_t* total = any + B;
+    const int passthrough = (min_area_ratio <= 0.0f && !keep_largest) ? 1 : 0;
+    const double min_area = (double)min_area_ratio * (double)d.P;
+    GGC_HIP(ctx, hipMemsetAsync(best, 0, sizeof(unsigned long long) * B * 2, st));
+    GGC_HIP(ctx, hipMemsetAsync(area, 0, sizeof(int32_t) * BP, st));
+    const dim3 g1(cdiv(BP, 256));
+    hipLaunchKernelGGL(k_cc_init, g1, dim3(256), 0, st, d, mask_in, parent, total);
+    if (!passthrough) {
+        hipLaunchKernelGGL(k_cc_merge, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(256), 0, st, d, parent);
+        hipLaunchKernelGGL(k_cc_area, g1, dim3(256), 0, st, d, parent, area);
+        hipLaunchKernelGGL(k_cc_best, g1, dim3(256), 0, st, d, min_area, parent, area, best, any);
+    }
+    hipLaunchKernelGGL(k_cc_apply, g1, dim3(256), 0, st, d, min_area, keep_largest, passthrough, mask_in, parent, area, best,
+                       any, total, mask_out);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
+
+extern "C" int ggc_compose_outputs(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, const uint8_t* bgr,
+                                   const uint8_t* binary, float alpha, int tint_b, int tint_g, int tint_r,
+                                   uint8_t* overlay, uint8_t* rgba) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, B >= 1 && H >= 1 && W >= 1, GGC_E_SHAPE, "bad shape B=%d H=%d W=%d", B, H, W);
+    GGC_REQUIRE(ctx, bgr && binary, GGC_E_INVALID_ARG, "null pointer");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(k_compose, dim3(cdiv(n, 256)), dim3(256), 0, st, n, bgr, binary, alpha, (float)tint_b, (float)tint_g,
+                       (float)tint_r, overlay, rgba);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
+
+extern "C" int ggc_mask_iou(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, const uint8_t* pred,
+                            const uint8_t* gt, double* iou) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, B >= 1 && H >= 1 && W >= 1 && B <= 65535, GGC_E_SHAPE, "bad shape B=%d H=%d W=%d", B, H, W);
+    GGC_REQUIRE(ctx, pred && gt && iou, GGC_E_INVALID_ARG, "null pointer");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const PDims d{B, H, W, H * W};
+    unsigned long long* cnt = scratch_t<unsigned long long>(ctx, S_CC_C, (size_t)B * 3);
+    if (!cnt) return GGC_E_OOM;
+    GGC_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * B * 3, st));
+    hipLaunchKernelGGL(k_iou_count, dim3(std::min(cdiv(d.P, 1024), 128), B), dim3(256), 0, st, d, pred, gt, cnt);
+    hipLaunchKernelGGL(k_iou_final, dim3(cdiv(B, 64)), dim3(64), 0, st, B, cnt, iou);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
