@@ -530,17 +530,19 @@ __global__ void __launch_bounds__(256) k_fill_nodes(GDims d, const int32_t* __re
     if (area) area[o] = st[li].area;
 }
 
-__global__ void __launch_bounds__(256) k_fill_edges(int B, const int64_t* __restrict__ pair_ptr, PairOut p,
+__global__ void __launch_bounds__(256) k_fill_edges(int B, const int64_t* __restrict__ pair_ptr,
+                                                    const int64_t* __restrict__ node_ptr, int global_ids, PairOut p,
                                                     const float* __restrict__ flag, int32_t* __restrict__ src,
                                                     int32_t* __restrict__ dst, float* __restrict__ attr) {
     const int b = blockIdx.y;
+    const int off = global_ids ? (int)node_ptr[b] : 0;      // PyG Batch collation offsets
     const int64_t beg = pair_ptr[b], end = pair_ptr[b + 1];
     const int64_t q = beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= end) return;
     const int64_t np = end - beg;
     const int64_t e0 = 2 * beg + (q - beg), e1 = e0 + np;   // [lo.., hi..] then mirrored (:303-306)
-    if (src) { src[e0] = p.lo[q]; src[e1] = p.hi[q]; }
-    if (dst) { dst[e0] = p.hi[q]; dst[e1] = p.lo[q]; }
+    if (src) { src[e0] = p.lo[q] + off; src[e1] = p.hi[q] + off; }
+    if (dst) { dst[e0] = p.hi[q] + off; dst[e1] = p.lo[q] + off; }
     if (attr) {
         const float a[5] = {p.de[q], p.dxy[q], p.shared[q], p.gc[q], flag[q]};
         for (int c = 0; c < 5; ++c) { attr[e0 * 5 + c] = a[c]; attr[e1 * 5 + c] = a[c]; }
@@ -665,7 +667,7 @@ extern "C" int ggc_graph_count(ggc_ctx* ctx, ggc_stream stream, int B, int H, in
 }
 
 extern "C" int ggc_graph_fill(ggc_ctx* ctx, ggc_stream stream, float* x, float* centroids, float* area_ratio,
-                              int32_t* edge_src, int32_t* edge_dst, float* edge_attr) {
+                              int32_t* edge_src, int32_t* edge_dst, float* edge_attr, int global_ids) {
     if (!ctx) return GGC_E_INVALID_ARG;
     GraphState& gs = ctx->graph;
     GGC_REQUIRE(ctx, gs.valid, GGC_E_STATE, "ggc_graph_fill without a preceding successful ggc_graph_count");
@@ -688,8 +690,8 @@ extern "C" int ggc_graph_fill(ggc_ctx* ctx, ggc_stream stream, float* x, float* 
                        reinterpret_cast<const float*>(ctx->slots[S_G_PRIOR].p),
                        reinterpret_cast<const RegionStats*>(ctx->slots[S_G_STATS].p), x, centroids, area_ratio);
     if (max_pairs > 0 && (edge_src || edge_dst || edge_attr))
-        hipLaunchKernelGGL(k_fill_edges, dim3(cdiv(max_pairs, 256), B), dim3(256), 0, st, B, ptrs + (B + 1), po, flag,
-                           edge_src, edge_dst, edge_attr);
+        hipLaunchKernelGGL(k_fill_edges, dim3(cdiv(max_pairs, 256), B), dim3(256), 0, st, B, ptrs + (B + 1), ptrs,
+                           global_ids, po, flag, edge_src, edge_dst, edge_attr);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
 }

@@ -144,11 +144,13 @@ __global__ void __launch_bounds__(256) k_iou_count(PDims d, const uint8_t* __res
         atomicAdd(&cnt[3 * b + 2], (unsigned long long)fn);
     }
 }
-__global__ void k_iou_final(int B, const unsigned long long* __restrict__ cnt, double* __restrict__ iou) {
+__global__ void k_iou_final(int B, const unsigned long long* __restrict__ cnt, double* __restrict__ iou,
+                            uint64_t* __restrict__ counts) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double tp = (double)cnt[3 * b], fp = (double)cnt[3 * b + 1], fn = (double)cnt[3 * b + 2];
-    iou[b] = tp / ((tp + fp + fn) + 1e-8);
+    if (iou) iou[b] = tp / ((tp + fp + fn) + 1e-8);
+    if (counts) { counts[3 * b] = cnt[3 * b]; counts[3 * b + 1] = cnt[3 * b + 1]; counts[3 * b + 2] = cnt[3 * b + 2]; }
 }
 
 } // namespace ggc
@@ -203,10 +205,10 @@ extern "C" int ggc_compose_outputs(ggc_ctx* ctx, ggc_stream stream, int B, int H
 }
 
 extern "C" int ggc_mask_iou(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, const uint8_t* pred,
-                            const uint8_t* gt, double* iou) {
+                            const uint8_t* gt, double* iou, uint64_t* counts) {
     if (!ctx) return GGC_E_INVALID_ARG;
     GGC_REQUIRE(ctx, B >= 1 && H >= 1 && W >= 1 && B <= 65535, GGC_E_SHAPE, "bad shape B=%d H=%d W=%d", B, H, W);
-    GGC_REQUIRE(ctx, pred && gt && iou, GGC_E_INVALID_ARG, "null pointer");
+    GGC_REQUIRE(ctx, pred && gt && (iou || counts), GGC_E_INVALID_ARG, "null pointer");
     GGC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const PDims d{B, H, W, H * W};
@@ -214,7 +216,7 @@ extern "C" int ggc_mask_iou(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W
     if (!cnt) return GGC_E_OOM;
     GGC_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * B * 3, st));
     hipLaunchKernelGGL(k_iou_count, dim3(std::min(cdiv(d.P, 1024), 128), B), dim3(256), 0, st, d, pred, gt, cnt);
-    hipLaunchKernelGGL(k_iou_final, dim3(cdiv(B, 64)), dim3(64), 0, st, B, cnt, iou);
+    hipLaunchKernelGGL(k_iou_final, dim3(cdiv(B, 64)), dim3(64), 0, st, B, cnt, iou, counts);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
 }

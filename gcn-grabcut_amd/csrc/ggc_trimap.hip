@@ -185,6 +185,30 @@ __global__ void __launch_bounds__(256) k_seed_apply(TDims d, const int32_t* __re
     if (s >= 0 && s < n && sel[n0 + s]) trimap[i] = (f & 1) ? GGC_PR_BGD : GGC_PR_FGD;
 }
 
+// standalone guided filter (pipeline.py:71-100): same box filter and op order as above
+__global__ void __launch_bounds__(256) k_gf_prep(size_t BP, const float* __restrict__ guide, const float* __restrict__ src,
+                                                 float* __restrict__ planes) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BP) return;
+    const float g = guide[i], s = src[i];
+    planes[i] = g; planes[BP + i] = s; planes[2 * BP + i] = g * s; planes[3 * BP + i] = g * g;
+}
+__global__ void __launch_bounds__(256) k_gf_ab(size_t BP, float eps, const float* __restrict__ m, float* __restrict__ ab) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BP) return;
+    const float mg = m[i], ms = m[BP + i];
+    const float cov = m[2 * BP + i] - mg * ms;
+    const float var = m[3 * BP + i] - mg * mg;
+    const float a = cov / (var + eps);
+    ab[i] = a;
+    ab[BP + i] = ms - a * mg;
+}
+__global__ void __launch_bounds__(256) k_gf_final(size_t BP, const float* __restrict__ guide, const float* __restrict__ mab,
+                                                  float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < BP) out[i] = mab[i] * guide[i] + mab[BP + i];
+}
+
 } // namespace ggc
 
 using namespace ggc;
@@ -221,6 +245,32 @@ extern "C" int ggc_refine_trimap(ggc_ctx* ctx, ggc_stream stream, int B, int H, 
     hipLaunchKernelGGL(k_blur_v, dim3(cdiv(BP * 4, 256)), dim3(256), 0, st, d, 4, radius, hs, means);
     hipLaunchKernelGGL(k_t_final, dim3(cdiv(BP, 256)), dim3(256), 0, st, BP, threshold_fg, threshold_bg, planes, means,
                        trimap);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
+
+extern "C" int ggc_guided_filter(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, const float* guide,
+                                 const float* src, int radius, float eps, float* out) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, B >= 1 && H >= 1 && W >= 1, GGC_E_SHAPE, "bad shape B=%d H=%d W=%d", B, H, W);
+    GGC_REQUIRE(ctx, guide && src && out, GGC_E_INVALID_ARG, "null pointer");
+    GGC_REQUIRE(ctx, radius >= 0 && radius <= 256, GGC_E_INVALID_ARG, "filter radius %d out of range", radius);
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const TDims d{B, H, W};
+    const size_t BP = (size_t)B * H * W;
+    float* planes = scratch_t<float>(ctx, S_T_A, BP * 6);
+    double* hs = scratch_t<double>(ctx, S_T_B, BP * 6);
+    float* means = scratch_t<float>(ctx, S_T_C, BP * 6);
+    if (!planes || !hs || !means) return GGC_E_OOM;
+    hipLaunchKernelGGL(k_gf_prep, dim3(cdiv(BP, 256)), dim3(256), 0, st, BP, guide, src, planes);
+    hipLaunchKernelGGL(k_blur_h, dim3(cdiv(BP * 4, 256)), dim3(256), 0, st, d, 4, radius, planes, hs);
+    hipLaunchKernelGGL(k_blur_v, dim3(cdiv(BP * 4, 256)), dim3(256), 0, st, d, 4, radius, hs, means);
+    float* ab = planes + BP;
+    hipLaunchKernelGGL(k_gf_ab, dim3(cdiv(BP, 256)), dim3(256), 0, st, BP, eps, means, ab);
+    hipLaunchKernelGGL(k_blur_h, dim3(cdiv(BP * 2, 256)), dim3(256), 0, st, d, 2, radius, ab, hs);
+    hipLaunchKernelGGL(k_blur_v, dim3(cdiv(BP * 2, 256)), dim3(256), 0, st, d, 2, radius, hs, means);
+    hipLaunchKernelGGL(k_gf_final, dim3(cdiv(BP, 256)), dim3(256), 0, st, BP, planes, means, out);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
 }

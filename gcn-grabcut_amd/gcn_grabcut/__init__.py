@@ -8,15 +8,26 @@ plotting are out of scope.
 """
 from ._constants import N_NODE_FEATS, N_EDGE_FEATS, N_PRIOR_FEATS, N_IMAGE_FEATS
 from .data import Data, Batch
+from .grabcut import GrabCut, GrabCutConfig, Label
+from .graph_builder import (
+    GraphBuilder, SuperpixelGraph, SuperpixelGraphConfig, compute_auto_prior, encode_user_hints,
+)
+from .metrics import evaluate, SegmentationMetrics
 from .model import (
     ResGCNNet, build_model, _probs_to_trimap, probs_to_node_trimap, project_to_pixels,
     TRIMAP_BG, TRIMAP_FG, TRIMAP_PROB_BG, TRIMAP_PROB_FG, CLASS_BG, CLASS_UNK, CLASS_FG,
 )
+from .pipeline import GCNGrabCutPipeline, SegmentationResult, clean_mask, guided_filter, refine_trimap
+from .synthetic import synthetic_image, synthetic_batch
 
 __version__ = "0.3.0+mi355x.1"
 
 __all__ = [
+    "GrabCut", "GrabCutConfig", "Label",
+    "GraphBuilder", "SuperpixelGraph", "SuperpixelGraphConfig", "compute_auto_prior", "encode_user_hints",
     "N_NODE_FEATS", "N_EDGE_FEATS", "N_PRIOR_FEATS",
-    "Data", "Batch",
+    "evaluate", "SegmentationMetrics",
+    "GCNGrabCutPipeline", "SegmentationResult", "clean_mask", "guided_filter", "refine_trimap",
     "ResGCNNet", "build_model", "probs_to_node_trimap", "project_to_pixels",
+    "Data", "Batch", "synthetic_image", "synthetic_batch",
 ]

@@ -36,7 +36,8 @@ SIGNATURES = {
     "ggc_preprocess": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ggc_slic": [_vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _i, _vp, _vp],
     "ggc_graph_count": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
-    "ggc_graph_fill": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ggc_graph_fill": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "ggc_guided_filter": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp],
     "ggc_resgcn_configure": [_vp, _i, _i],
     "ggc_resgcn_load_weight": [_vp, C.c_char_p, _vp, _i64],
     "ggc_resgcn_ready": [_vp],
@@ -48,7 +49,7 @@ SIGNATURES = {
     "ggc_grabcut": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _u64, _vp],
     "ggc_clean_mask": [_vp, _vp, _i, _i, _i, _vp, _f, _i, _vp],
     "ggc_compose_outputs": [_vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp],
-    "ggc_mask_iou": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "ggc_mask_iou": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"ggc_last_error": C.c_char_p}
 

@@ -1,0 +1,234 @@
+"""
+GCN-GrabCut end-to-end pipeline — host mirror of reference src/gcn_grabcut/pipeline.py.
+
+  1. superpixel graph (+ automatic FG/BG prior)      ggc_preprocess, ggc_slic, ggc_graph_*
+  2. ResGCNNet -> region probabilities               ggc_resgcn_forward
+  3. guided-filter projection -> pixel trimap        ggc_refine_trimap (+ ggc_seed_from_prior)
+  4. GrabCut refinement -> binary mask               ggc_grabcut
+  5. clean-up and output composition                 ggc_clean_mask, ggc_compose_outputs
+
+`segment(image)` keeps the reference signature and result type; `segment_batch`
+(additive) runs the same stages over a batch of equally sized images with every
+intermediate resident in HBM.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .grabcut import GrabCut, GrabCutConfig, Label
+from .graph_builder import GraphBuilder, SuperpixelGraphConfig, graphs_to_host, _check_image
+from .metrics import evaluate, SegmentationMetrics
+from .model import CLASS_BG, CLASS_FG, project_to_pixels  # noqa: F401
+
+
+def _write_png(path: str, array: np.ndarray) -> None:
+    """cv2.imwrite stand-in (OpenCV is not a dependency): BGR(A) array -> PNG via Pillow."""
+    from PIL import Image
+    a = np.asarray(array)
+    if a.ndim == 3 and a.shape[2] == 3:
+        a = a[:, :, ::-1]
+    elif a.ndim == 3 and a.shape[2] == 4:
+        a = a[:, :, [2, 1, 0, 3]]
+    Image.fromarray(np.ascontiguousarray(a)).save(path)
+
+
+@dataclass
+class SegmentationResult:
+    """All outputs from one pipeline run (reference pipeline.py:32-68)."""
+    image: np.ndarray          # original BGR
+    binary_mask: np.ndarray    # (H, W) uint8 {0, 1}
+    trimap: np.ndarray         # (H, W) uint8 {0,1,2,3}
+    segments: np.ndarray       # (H, W) superpixel map
+    overlay: np.ndarray        # BGR with coloured overlay
+    rgba: np.ndarray           # BGRA transparent background
+    timing: dict = field(default_factory=dict)
+
+    def save(self, prefix: str = "result") -> None:
+        _write_png(f"{prefix}_overlay.png", self.overlay)
+        _write_png(f"{prefix}_rgba.png", self.rgba)
+        _write_png(f"{prefix}_trimap_colour.png", _colour_trimap(self.trimap))
+        _write_png(f"{prefix}_mask.png", self.binary_mask * 255)
+        print(f"Saved outputs with prefix: {prefix}")
+
+    def evaluate_against(self, gt_mask: np.ndarray) -> SegmentationMetrics:
+        """Segmentation metrics against a ground-truth mask (the reference also returns
+        trimap metrics, which are evaluation extras outside this build's scope)."""
+        return evaluate(self.binary_mask, gt_mask)
+
+
+def guided_filter(guide: np.ndarray, src: np.ndarray, radius: int = 8, eps: float = 1e-3, device="cuda") -> np.ndarray:
+    """Edge-preserving filter of `src` under `guide` (He et al.) — reference pipeline.py:71-100."""
+    from ._engine import get_engine
+    eng = get_engine(device)
+    g = eng.to_device(np.ascontiguousarray(guide, dtype=np.float32)[None])
+    s = eng.to_device(np.ascontiguousarray(src, dtype=np.float32)[None])
+    return eng.guided_filter(g, s, radius, eps)[0].cpu().numpy()
+
+
+def refine_trimap(probs: np.ndarray, segments: np.ndarray, image: np.ndarray, threshold_fg: float = 0.55,
+                  threshold_bg: float = 0.55, radius: int = 8, eps: float = 1e-3, device="cuda") -> np.ndarray:
+    """Region probabilities -> pixel trimap whose boundaries follow image edges
+    (reference pipeline.py:103-146)."""
+    from ._engine import get_engine
+    eng = get_engine(device)
+    p = eng.to_device(np.ascontiguousarray(probs, dtype=np.float32))
+    node_ptr = eng.to_device(np.array([0, probs.shape[0]], np.int32))
+    seg = eng.to_device(np.ascontiguousarray(segments, dtype=np.int32)[None])
+    bgr = eng.to_device(_check_image(image)[None])
+    return eng.refine_trimap(p, node_ptr, seg, bgr, threshold_fg, threshold_bg, radius, eps, True)[0].cpu().numpy()
+
+
+def _seed_from_prior(trimap: np.ndarray, graph, seed_frac: float = 0.1, device="cuda") -> np.ndarray:
+    """Guarantee a foreground and a background seed (reference pipeline.py:149-186)."""
+    from ._engine import get_engine
+    prior = graph.prior_features
+    if prior is None or prior.size == 0:
+        return trimap
+    eng = get_engine(device)
+    t = eng.to_device(np.ascontiguousarray(trimap, dtype=np.uint8)[None]).clone()
+    p = eng.to_device(np.ascontiguousarray(prior, dtype=np.float32))
+    node_ptr = eng.to_device(np.array([0, graph.n_nodes], np.int32))
+    seg = eng.to_device(np.ascontiguousarray(graph.segments, dtype=np.int32)[None])
+    return eng.seed_from_prior(t, p, node_ptr, seg, seed_frac)[0].cpu().numpy()
+
+
+def clean_mask(mask: np.ndarray, min_area_ratio: float = 0.002, keep_largest: bool = False, device="cuda") -> np.ndarray:
+    """Remove spurious connected components (reference pipeline.py:189-227)."""
+    from ._engine import get_engine
+    eng = get_engine(device)
+    m = eng.to_device(np.ascontiguousarray(mask, dtype=np.uint8)[None])
+    return eng.clean_mask(m, min_area_ratio, keep_largest)[0].cpu().numpy()
+
+
+def _colour_trimap(trimap: np.ndarray) -> np.ndarray:
+    """reference pipeline.py:230-236"""
+    vis = np.zeros((*trimap.shape, 3), dtype=np.uint8)
+    vis[trimap == Label.BG_DEFINITE] = [0, 0, 0]
+    vis[trimap == Label.FG_DEFINITE] = [255, 255, 255]
+    vis[trimap == Label.BG_PROBABLE] = [60, 20, 20]
+    vis[trimap == Label.FG_PROBABLE] = [0, 200, 200]
+    return vis
+
+
+class GCNGrabCutPipeline:
+    """
+    Full GCN-GrabCut segmentation pipeline on the MI355X (reference pipeline.py:239-380).
+
+    model     : trimap predictor (ResGCNNet)
+    sp_config : SuperpixelGraphConfig (default 300 segments)
+    gc_config : GrabCutConfig (default 5 iterations)
+    device    : "cuda" / "cuda:<i>"
+    """
+
+    def __init__(self, model, sp_config: Optional[SuperpixelGraphConfig] = None,
+                 gc_config: Optional[GrabCutConfig] = None, device: str = "cuda"):
+        from ._engine import get_engine
+        self._eng = get_engine(device)
+        self.model = model.to(self._eng.device)
+        self.device = device
+        self.sp_config = sp_config or SuperpixelGraphConfig()
+        self.gc_config = gc_config or GrabCutConfig()
+
+    # ------------------------------------------------------------ batched, device resident
+    def segment_batch_device(self, bgr, threshold_fg: float = 0.55, threshold_bg: float = 0.55,
+                             refine_iters: int = 0, min_area_ratio: float = 0.002, keep_largest: bool = False,
+                             edge_aware: bool = True, filter_radius: int = 8, compose: bool = True,
+                             timing: Optional[dict] = None) -> dict:
+        """bgr: (B,H,W,3) uint8 tensor on the pipeline's device.  Returns device tensors."""
+        import torch
+        eng, cfg = self._eng, self.sp_config
+        if self.gc_config.color_space.lower() != "rgb":
+            raise NotImplementedError("only color_space='rgb' is on the MI355X hot path")
+        if not cfg.use_lab:
+            raise NotImplementedError("use_lab=False is not on the MI355X hot path")
+
+        def tick():
+            if timing is not None:
+                torch.cuda.synchronize(eng.device)
+            return time.perf_counter()
+
+        t = tick()
+        lab, hsv, gray, grad = eng.preprocess(bgr)
+        seg, n_nodes = eng.slic(lab, cfg.n_segments, cfg.compactness, cfg.sigma)
+        graphs = eng.build_graphs(seg, n_nodes, lab, hsv, grad, cfg.connectivity, cfg.n_nonlocal)
+        if timing is not None:
+            timing["graph_build"] = tick() - t
+            timing["data_prep"] = 0.0          # the graph is already in HBM: nothing to copy
+
+        t = tick()
+        self.model.eval()
+        probs = eng.predict_probs(self.model, graphs)
+        trimap = eng.refine_trimap(probs, graphs.node_ptr, seg, bgr, threshold_fg, threshold_bg, filter_radius,
+                                   1e-3, edge_aware)
+        if timing is not None:
+            timing["gcn_inference"] = tick() - t
+        trimap = eng.seed_from_prior(trimap, graphs.x[:, 16:19], graphs.node_ptr, seg, 0.1)
+
+        t = tick()
+        mask = trimap.clone()
+        binary, mask, bgd, fgd = eng.grabcut(bgr, mask, self.gc_config.n_iter, 0, None, self.gc_config.seed)
+        if refine_iters > 0:
+            binary, mask, bgd, fgd = eng.grabcut(bgr, mask, refine_iters, 2, None, self.gc_config.seed, bgd, fgd)
+        if timing is not None:
+            timing["grabcut"] = tick() - t
+
+        t = tick()
+        cleaned = eng.clean_mask(binary, min_area_ratio, keep_largest)
+        out = {"binary_mask": cleaned, "trimap": trimap, "segments": seg, "graphs": graphs, "probs": probs,
+               "gc_mask": mask}
+        if compose:
+            out["overlay"], out["rgba"] = eng.compose(bgr, cleaned)
+        if timing is not None:
+            timing["postprocess"] = tick() - t
+        return out
+
+    def segment_batch(self, images: Sequence[np.ndarray], **kwargs) -> list[SegmentationResult]:
+        """Segment equally sized BGR images as one batch (additive API)."""
+        imgs = [_check_image(im) for im in images]
+        if not imgs:
+            return []
+        if any(im.shape != imgs[0].shape for im in imgs):
+            raise ValueError("segment_batch needs images of one size; group them by shape")
+        timing: dict[str, float] = {}
+        bgr = self._eng.to_device(np.stack(imgs))
+        out = self.segment_batch_device(bgr, timing=timing, **kwargs)
+        host = {k: out[k].cpu().numpy() for k in ("binary_mask", "trimap", "segments", "overlay", "rgba")}
+        per_image = {k: v / len(imgs) for k, v in timing.items()}
+        return [SegmentationResult(image=imgs[i], binary_mask=host["binary_mask"][i], trimap=host["trimap"][i],
+                                   segments=host["segments"][i], overlay=host["overlay"][i], rgba=host["rgba"][i],
+                                   timing=dict(per_image)) for i in range(len(imgs))]
+
+    # ------------------------------------------------------------ reference API
+    def segment(self, image: np.ndarray, threshold_fg: float = 0.55, threshold_bg: float = 0.55,
+                refine_iters: int = 0, min_area_ratio: float = 0.002, keep_largest: bool = False,
+                edge_aware: bool = True, filter_radius: int = 8) -> SegmentationResult:
+        """Full pipeline on one BGR image (reference pipeline.py:265-352)."""
+        image = _check_image(image)
+        timing: dict[str, float] = {}
+        out = self.segment_batch_device(self._eng.to_device(image[None]), threshold_fg, threshold_bg, refine_iters,
+                                        min_area_ratio, keep_largest, edge_aware, filter_radius, timing=timing)
+        return SegmentationResult(
+            image=image, binary_mask=out["binary_mask"][0].cpu().numpy(), trimap=out["trimap"][0].cpu().numpy(),
+            segments=out["segments"][0].cpu().numpy(), overlay=out["overlay"][0].cpu().numpy(),
+            rgba=out["rgba"][0].cpu().numpy(), timing=timing)
+
+    def segment_bbox(self, image: np.ndarray, bbox: tuple[int, int, int, int]) -> SegmentationResult:
+        """Classical GrabCut with a bounding box (reference pipeline.py:354-380)."""
+        image = _check_image(image)
+        gc = GrabCut(image, self.gc_config, device=self.device)
+        binary_mask = gc.run_with_bbox(bbox)
+        x, y, w, h = bbox
+        H, W = image.shape[:2]
+        trimap = np.full((H, W), Label.BG_PROBABLE, dtype=np.uint8)
+        trimap[y:y + h, x:x + w] = Label.FG_PROBABLE
+        # 30x30 erosion of the box (anchor at the centre, as cv2.erode): shrink by 15 / 14 pixels
+        y0, y1, x0, x1 = max(y, 0) + 15, min(y + h, H) - 14, max(x, 0) + 15, min(x + w, W) - 14
+        if y1 > y0 and x1 > x0:
+            trimap[y0:y1, x0:x1] = Label.FG_DEFINITE
+        return SegmentationResult(image=image, binary_mask=binary_mask, trimap=trimap,
+                                  segments=np.zeros((H, W), dtype=np.int32), overlay=gc.overlay_mask(),
+                                  rgba=gc.crop_foreground())

@@ -126,11 +126,13 @@ int ggc_graph_count(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
  *              reference's order: [adjacency pairs sorted, non-local pairs
  *              sorted] then the mirrored copy (graph_builder.py:303-306)
  *   edge_attr  [dev] f32 [E_total,5]
- * Any output pointer may be NULL to skip it.
+ * Any output pointer may be NULL to skip it.  global_ids != 0 adds each image's
+ * node offset to the edge endpoints (PyG Batch collation), which is the form
+ * ggc_resgcn_forward consumes.
  */
 int ggc_graph_fill(ggc_ctx* ctx, ggc_stream stream,
                    float* x, float* centroids, float* area_ratio,
-                   int32_t* edge_src, int32_t* edge_dst, float* edge_attr);
+                   int32_t* edge_src, int32_t* edge_dst, float* edge_attr, int global_ids);
 
 /* ------------------------------------------------------------ M0-M7 ResGCNNet
  * Replaces ResGCNNet (model.py:421-557), eval mode.
@@ -192,6 +194,11 @@ int ggc_refine_trimap(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                       float threshold_fg, float threshold_bg,
                       int radius, float eps, int edge_aware, uint8_t* trimap);
 
+/* P1 alone — replaces guided_filter (pipeline.py:71-100) for callers that use it
+ * directly.  guide, src, out [dev] f32 [B,H,W]. */
+int ggc_guided_filter(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
+                      const float* guide, const float* src, int radius, float eps, float* out);
+
 /* S0 — replaces _seed_from_prior (pipeline.py:149-186); in place on trimap.
  *   prior [dev] f32 [N_total,3] (columns 16..18 of x, contiguous copy) */
 int ggc_seed_from_prior(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
@@ -230,9 +237,9 @@ int ggc_compose_outputs(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                         uint8_t* overlay, uint8_t* rgba);
 
 /* R0 — IoU = tp / (tp + fp + fn + 1e-8) per image (metrics.py:79-84).
- *   iou [dev] f64 [B] */
+ *   iou [dev] f64 [B] (may be NULL)   counts [dev] u64 [B,3] = tp, fp, fn (may be NULL) */
 int ggc_mask_iou(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
-                 const uint8_t* pred, const uint8_t* gt, double* iou);
+                 const uint8_t* pred, const uint8_t* gt, double* iou, uint64_t* counts);
 
 #ifdef __cplusplus
 }

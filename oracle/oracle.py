@@ -318,3 +318,34 @@ def iou(pred, gt):
     pred = np.ascontiguousarray(pred, dtype=np.uint8)
     gt = np.ascontiguousarray(gt, dtype=np.uint8)
     return float(L.ggo_iou(_i(pred.size), _p(pred), _p(gt)))
+
+
+# ---------------------------------------------------------------- the whole path
+
+def segment(bgr, state, hidden, n_layers, n_segments=300, compactness=10.0, sigma=1.0, connectivity=4,
+            n_nonlocal=4, threshold_fg=0.55, threshold_bg=0.55, n_iter=5, refine_iters=0, min_area_ratio=0.002,
+            keep_largest=False, edge_aware=True, filter_radius=8, seed=0, timing=None):
+    """CPU restatement of GCNGrabCutPipeline.segment (reference pipeline.py:265-352), stage by stage.
+    `state` is the ResGCNNet state_dict as numpy arrays.  Returns a dict of host arrays."""
+    import time
+    t0 = time.perf_counter()
+    lab, hsv, gray, grad = preprocess(bgr)
+    seg, n = slic(lab, n_segments, compactness, sigma, True)
+    g = graph_build(seg, lab, hsv, grad, connectivity, n_nonlocal)
+    t1 = time.perf_counter()
+    x = np.concatenate([g["node_features"], g["prior"]], 1)
+    logits, probs = resgcn_forward(state, hidden, n_layers, x, g["edge_index"], g["edge_attr"])
+    trimap = refine_trimap(probs, seg, bgr, threshold_fg, threshold_bg, filter_radius, 1e-3, edge_aware)
+    t2 = time.perf_counter()
+    trimap = seed_from_prior(trimap, g["prior"], seg, 0.1)
+    binary, mask, bgd, fgd, rc = grabcut(bgr, trimap, n_iter, 0, None, seed)
+    if refine_iters > 0 and rc == 0:
+        binary, mask, bgd, fgd, _ = grabcut(bgr, mask, refine_iters, 2, None, seed, bgd, fgd)
+    t3 = time.perf_counter()
+    cleaned = clean_mask(binary, min_area_ratio, keep_largest)
+    overlay, rgba = compose(bgr, cleaned)
+    t4 = time.perf_counter()
+    if timing is not None:
+        timing.update(graph_build=t1 - t0, gcn_inference=t2 - t1, grabcut=t3 - t2, postprocess=t4 - t3)
+    return dict(segments=seg, n_nodes=n, graph=g, x=x, logits=logits, probs=probs, trimap=trimap,
+                binary_mask=cleaned, gc_mask=mask, overlay=overlay, rgba=rgba)

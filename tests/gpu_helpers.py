@@ -32,7 +32,7 @@ def slic(ctx, lab, n_segments, compactness=10.0, sigma=1.0, rescale=1):
     return seg, n
 
 
-def graph(ctx, seg, n_nodes, lab, hsv, grad, connectivity=4, n_nonlocal=4):
+def graph(ctx, seg, n_nodes, lab, hsv, grad, connectivity=4, n_nonlocal=4, global_ids=False):
     """-> dict with packed device tensors + host node_ptr / edge_ptr."""
     b, h, w = seg.shape
     node_ptr = np.zeros(b + 1, np.int64)
@@ -45,5 +45,5 @@ def graph(ctx, seg, n_nodes, lab, hsv, grad, connectivity=4, n_nonlocal=4):
                area=torch.empty(n, device="cuda"), src=torch.empty(max(e, 1), dtype=torch.int32, device="cuda"),
                dst=torch.empty(max(e, 1), dtype=torch.int32, device="cuda"), attr=torch.empty(max(e, 1), 5, device="cuda"))
     ctx.call("ggc_graph_fill", stream(), out["x"].data_ptr(), out["centroids"].data_ptr(), out["area"].data_ptr(),
-             out["src"].data_ptr(), out["dst"].data_ptr(), out["attr"].data_ptr())
+             out["src"].data_ptr(), out["dst"].data_ptr(), out["attr"].data_ptr(), int(global_ids))
     return out

@@ -116,8 +116,11 @@ def test_clean_mask_compose_iou_bit_exact(oracle, gpu_ctx):
                  ov.data_ptr(), rgba.data_ptr())
     iou = torch.empty(b, dtype=torch.float64, device="cuda")
     other = torch.as_tensor(np.roll(masks, 3, axis=2)).cuda()
-    gpu_ctx.call("ggc_mask_iou", gh.stream(), b, h, w, dm.data_ptr(), other.data_ptr(), iou.data_ptr())
+    cnt = torch.empty(b, 3, dtype=torch.int64, device="cuda")
+    gpu_ctx.call("ggc_mask_iou", gh.stream(), b, h, w, dm.data_ptr(), other.data_ptr(), iou.data_ptr(), cnt.data_ptr())
     for i in range(b):
         wo, wr = oracle.compose(img[i], masks[i])
         assert np.array_equal(ov[i].cpu().numpy(), wo) and np.array_equal(rgba[i].cpu().numpy(), wr)
-        assert iou[i].item() == pytest.approx(oracle.iou(masks[i], np.roll(masks, 3, axis=2)[i]), abs=1e-12)
+        o = np.roll(masks, 3, axis=2)[i]
+        assert iou[i].item() == pytest.approx(oracle.iou(masks[i], o), abs=1e-12)
+        assert cnt[i].tolist() == [int((masks[i] & o).sum()), int((masks[i] & (1 - o)).sum()), int(((1 - masks[i]) & o).sum())]

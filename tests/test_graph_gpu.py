@@ -67,5 +67,5 @@ def test_graph_fill_requires_count(gpu_ctx):
     from gcn_grabcut import _native
     fresh = _native.Context(0)
     with pytest.raises(_native.GGCError, match="GGC_E_STATE"):
-        fresh.call("ggc_graph_fill", 0, None, None, None, None, None, None)
+        fresh.call("ggc_graph_fill", 0, None, None, None, None, None, None, 0)
     fresh.close()

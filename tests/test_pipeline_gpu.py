@@ -1,0 +1,151 @@
+"""GPU end-to-end parity: GCNGrabCutPipeline (host mirror + HIP kernels) against
+the CPU oracle chain, with the parity gates of SURVEY section 8(d); plus the
+reference's own API-level tests (tests/test.py) re-expressed for this build."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _np_state(sd):
+    return {k: v.numpy() for k, v in sd.items() if v.dtype.is_floating_point}
+
+
+def _img(h=64, w=64, seed=42):
+    return np.random.RandomState(seed).randint(20, 220, (h, w, 3), dtype=np.uint8)   # reference tests/test.py:17-19
+
+
+@pytest.fixture(scope="module")
+def pipe128():
+    from gcn_grabcut import GCNGrabCutPipeline, SuperpixelGraphConfig
+    model, sd = seeded_state_dict(128, 6, seed=0)
+    return GCNGrabCutPipeline(model.eval(), sp_config=SuperpixelGraphConfig(n_segments=600), device="cuda"), sd
+
+
+def test_full_pipeline_matches_oracle_on_duts_shape_batch(oracle, pipe128):
+    from gcn_grabcut.synthetic import synthetic_batch
+    pipe, sd = pipe128
+    imgs = synthetic_batch(3, 300, 400, config_id=3)
+    res = pipe.segment_batch(list(imgs))
+    out = pipe.segment_batch_device(pipe._eng.to_device(imgs))
+    g = out["graphs"]
+    st = _np_state(sd)
+    for i in range(3):
+        want = oracle.segment(imgs[i], st, 128, 6, n_segments=600, seed=i)
+        r = res[i]
+        assert np.array_equal(r.segments, want["segments"])                       # label map: bit-exact
+        n0, n1, e0, e1 = g.node_ptr_host[i], g.node_ptr_host[i + 1], g.edge_ptr_host[i], g.edge_ptr_host[i + 1]
+        ei = np.stack([g.edge_src[e0:e1].cpu().numpy(), g.edge_dst[e0:e1].cpu().numpy()]).astype(np.int64) - n0
+        assert np.array_equal(ei, want["graph"]["edge_index"])                    # edge_index: integer-exact
+        assert np.abs(g.x[n0:n1].cpu().numpy() - want["x"]).max() <= 2e-5
+        assert np.abs(out["probs"][n0:n1].cpu().numpy() - want["probs"]).max() <= 1e-4   # north star: 1e-4 on GCN outputs
+        tri_match = (r.trimap == want["trimap"]).mean()
+        assert tri_match >= 0.9999, tri_match                                     # trimap: exact up to 1e-4 logit noise
+        if tri_match == 1.0:
+            assert np.array_equal(r.binary_mask, want["binary_mask"])             # then the mask is bit-exact too
+        assert oracle.iou(r.binary_mask, want["binary_mask"]) >= 0.99 or want["binary_mask"].sum() == 0
+        assert r.overlay.shape == (300, 400, 3) and r.rgba.shape == (300, 400, 4)
+        assert set(np.unique(r.binary_mask)) <= {0, 1} and set(np.unique(r.trimap)) <= {0, 1, 2, 3}
+
+
+def test_segment_returns_result_like_reference():
+    # reference tests/test.py:435-448
+    from gcn_grabcut.model import ResGCNNet
+    from gcn_grabcut.pipeline import GCNGrabCutPipeline
+    img = _img(100, 100)
+    pipeline = GCNGrabCutPipeline(ResGCNNet(hidden_channels=32, n_layers=2).eval(), device="cuda")
+    result = pipeline.segment(img)
+    assert result.binary_mask.shape == (100, 100) and result.trimap.shape == (100, 100)
+    assert result.overlay.shape == (100, 100, 3) and result.rgba.shape == (100, 100, 4)
+    for key in ("graph_build", "data_prep", "gcn_inference", "grabcut", "postprocess"):
+        assert key in result.timing
+    m = result.evaluate_against((np.indices((100, 100)).sum(0) % 2).astype(np.uint8))
+    assert 0 <= m.iou <= 1
+    r2 = pipeline.segment(img, edge_aware=False, keep_largest=True, refine_iters=1)
+    assert r2.binary_mask.shape == (100, 100)
+    rb = pipeline.segment_bbox(img, (10, 10, 80, 80))
+    assert rb.binary_mask.shape == (100, 100) and (rb.trimap[30:60, 30:60] == 1).all()
+
+
+def test_graph_builder_like_reference(oracle):
+    # reference tests/test.py:87-155
+    from gcn_grabcut.graph_builder import GraphBuilder, SuperpixelGraphConfig, N_EDGE_FEATS, N_NODE_FEATS, encode_user_hints
+    img = _img(64, 64)
+    graph = GraphBuilder(img, SuperpixelGraphConfig(n_segments=50)).build()
+    assert graph.n_nodes > 0 and graph.node_features.shape == (graph.n_nodes, 16)
+    assert graph.edge_index.shape[0] == 2 and graph.n_edges == graph.edge_index.shape[1]
+    assert graph.edge_index.dtype == np.int64 and graph.segments.dtype == np.int32
+    graph = GraphBuilder(img).build()
+    assert graph.node_features[:, :6].min() >= -0.01 and graph.node_features[:, :6].max() <= 1.01
+    assert graph.edge_attr.shape == (graph.n_edges, N_EDGE_FEATS)
+    assert np.unique(graph.segments).min() == 0 and np.unique(graph.segments).max() == graph.n_nodes - 1
+    prior = graph.prior_features
+    assert prior.shape == (graph.n_nodes, 3) and np.isfinite(prior).all() and prior.min() >= -1e-5 and prior.max() <= 1 + 1e-5
+    assert graph.node_input().shape == (graph.n_nodes, N_NODE_FEATS)
+    hints = encode_user_hints(graph.segments, [(32, 32)], [(2, 2)])
+    assert hints[int(graph.segments[32, 32]), 0] == 1.0 and hints[int(graph.segments[2, 2]), 1] == 1.0
+    for conn in (4, 8):
+        assert GraphBuilder(img, SuperpixelGraphConfig(n_segments=50, connectivity=conn)).build().n_edges > 0
+    # the whole builder equals the oracle chain
+    lab, hsv, gray, grad = oracle.preprocess(img)
+    seg, n = oracle.slic(lab, 300)
+    want = oracle.graph_build(seg, lab, hsv, grad)
+    assert np.array_equal(graph.segments, seg) and np.array_equal(graph.edge_index, want["edge_index"])
+    from gcn_grabcut.graph_builder import compute_auto_prior
+    assert np.abs(compute_auto_prior(seg, lab) - want["prior"]).max() <= 2e-5
+
+
+def test_grabcut_class_like_reference(oracle):
+    # reference tests/test.py:31-82
+    from gcn_grabcut.grabcut import GrabCut, GrabCutConfig
+    img = _img(100, 100)
+    gc = GrabCut(img, GrabCutConfig(n_iter=1))
+    mask = gc.run_with_bbox((10, 10, 80, 80))
+    assert mask.shape == (100, 100) and set(np.unique(mask)) <= {0, 1}
+    assert len(gc.history) == 1 and 0 <= gc.history[0].fg_ratio <= 1
+    assert gc.overlay_mask().shape == (100, 100, 3) and gc.crop_foreground().shape == (100, 100, 4)
+    tri = np.full((100, 100), 2, np.uint8); tri[30:70, 30:70] = 3
+    gc2 = GrabCut(img, GrabCutConfig(n_iter=1))
+    m2 = gc2.run_with_trimap(tri)
+    wb, *_ = oracle.grabcut(img, tri, 1, 0)
+    assert np.array_equal(m2, wb)
+    m3 = gc2.refine(1)
+    assert m3.shape == (100, 100) and len(gc2.history) == 2
+    with pytest.raises(ValueError):
+        gc2.run_with_trimap(np.zeros((10, 10), np.uint8))
+    with pytest.raises(RuntimeError):
+        GrabCut(img).refine(1)
+    with pytest.raises(NotImplementedError):
+        GrabCut(img, GrabCutConfig(color_space="hsv"))
+
+
+def test_helper_functions_match_oracle(oracle):
+    from gcn_grabcut import guided_filter, refine_trimap, clean_mask, evaluate
+    rng = np.random.default_rng(0)
+    guide = rng.random((40, 56)).astype(np.float32)
+    src = rng.random((40, 56)).astype(np.float32)
+    assert np.array_equal(guided_filter(guide, src, 4, 1e-3), oracle.guided_filter(guide, src, 4, 1e-3))
+    seg = (np.arange(40 * 56).reshape(40, 56) // 280).astype(np.int32)
+    probs = rng.dirichlet([1, 1, 1], size=8).astype(np.float32)
+    img = _img(40, 56)
+    assert np.array_equal(refine_trimap(probs, seg, img), oracle.refine_trimap(probs, seg, img))
+    m = (rng.random((40, 56)) < 0.1).astype(np.uint8); m[5:20, 5:30] = 1
+    assert np.array_equal(clean_mask(m, 0.01), oracle.clean_mask(m, 0.01))
+    ev = evaluate(m, np.roll(m, 2, 1))
+    assert ev.iou == pytest.approx(oracle.iou(m, np.roll(m, 2, 1)), abs=1e-9)
+    assert evaluate(m, m).iou == pytest.approx(1.0, abs=1e-4) and evaluate(np.zeros_like(m), m).iou < 0.01
+
+
+def test_one_sided_trimap_is_reseeded_and_cpu_device_is_refused():
+    from gcn_grabcut.model import ResGCNNet
+    from gcn_grabcut.pipeline import GCNGrabCutPipeline
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GCNGrabCutPipeline(ResGCNNet(hidden_channels=32, n_layers=2), device="cpu")
+    with torch.no_grad():
+        model = ResGCNNet(hidden_channels=32, n_layers=2).eval()
+        model.head.bias.copy_(torch.tensor([-20.0, -20.0, 20.0]))     # everything "foreground"
+    res = GCNGrabCutPipeline(model, device="cuda").segment(_img(80, 80))
+    assert set(np.unique(res.trimap)) & {0, 2}                        # _seed_from_prior put background back
