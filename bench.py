@@ -5,12 +5,18 @@ bench.py — throughput of the GCN-GrabCut hot path on MI355X.
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
 A "step" is one pass of the hot path over one per-GPU batch of synthetic
-DUTS-shaped input, already resident in HBM.  Prints ONE JSON line on rank 0:
-BASELINE.json's metric (images/s), the roofline of the dominant kernel (the
-GCNConv scatter-gather, timed with HIP events on its launch stream inside the
-timed region) and the CPU oracle timed on a bounded sample of the same
-workload.  Weights are a seeded random init (no checkpoint ships with the
-reference); data is synthetic.
+DUTS-shaped images that are already resident in HBM:
+
+    --workload full  (default)  configs[2]: SLIC -> graph -> ResGCNNet -> guided-filter
+                                trimap -> GrabCut -> clean-up, batch 256 of 400x300 per GPU
+    --workload gcn              configs[1]: ResGCNNet forward only on 64 pre-built graphs
+
+Rank 0 prints ONE JSON line: BASELINE.json's metric (images/s), the roofline of
+the dominant kernel named by the north star (the GCNConv scatter-gather, timed
+with HIP events on its launch stream inside the timed region), parity against
+the CPU oracle on a sample, and the oracle timed on that bounded sample.
+Weights are a seeded random init (the reference ships no checkpoint).  Images
+shard across ranks with no data-path collective; RCCL only gathers the timing.
 """
 from __future__ import annotations
 
@@ -30,19 +36,19 @@ for _p in (ROOT, ROOT / "src"):
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 HIDDEN, LAYERS = 128, 6    # ResGCNNet default (reference model.py:453-454)
+H, W, N_SEGMENTS = 300, 400, 600
 
 
 def synthetic_region_graph(n: int, rng: np.random.Generator, k_nl: int = 4):
-    """Region graph of DUTS shape without running SLIC: jittered grid of n regions,
-    4-neighbour adjacency + a third of the diagonals (shared corners), k non-local
-    colour neighbours per node, mirrored as in reference graph_builder.py:303-306.
-    n = 600 gives E ~ 6.4k directed edges (N ~ 601, E ~ 6.46k)."""
+    """Region graph of DUTS shape without running SLIC (for --workload gcn): jittered grid of
+    n regions, 4-neighbour adjacency + most diagonals, k non-local colour neighbours per node,
+    mirrored as in reference graph_builder.py:303-306.  n = 600 -> E ~ 6.4k directed edges."""
     gw = int(round(np.sqrt(n * 4 / 3)))
     gh = int(np.ceil(n / gw))
     ids = np.arange(gh * gw).reshape(gh, gw)
     lo, hi = [], []
     for a, b, p in ((ids[:, :-1], ids[:, 1:], 1.0), (ids[:-1, :], ids[1:, :], 1.0),
-                    (ids[:-1, :-1], ids[1:, 1:], 0.35)):
+                    (ids[:-1, :-1], ids[1:, 1:], 0.9)):
         ok = (a < n) & (b < n) & (rng.random(a.shape) < p)
         lo.append(np.minimum(a[ok], b[ok])); hi.append(np.maximum(a[ok], b[ok]))
     lo, hi = np.concatenate(lo), np.concatenate(hi)
@@ -77,11 +83,13 @@ def agg_bytes(n_nodes: int, n_edges: int, d: int, n_graphs: int) -> int:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="graphs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["full", "gcn"], default="full")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default 256 full / 64 gcn)")
+    ap.add_argument("--cpu-sample", type=int, default=6, help="images timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
+    batch_size = args.batch or (256 if args.workload == "full" else 64)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -98,25 +106,36 @@ def main() -> None:
 
     from gcn_grabcut import _native
     from gcn_grabcut.data import Batch, Data
+    from gcn_grabcut.graph_builder import SuperpixelGraphConfig
     from gcn_grabcut.model import ResGCNNet
+    from gcn_grabcut.pipeline import GCNGrabCutPipeline
+    from gcn_grabcut.synthetic import synthetic_batch
 
     # ---- model: seeded random init (reference model.py:501-506); no checkpoint ships
     torch.manual_seed(0)
     model = ResGCNNet(hidden_channels=HIDDEN, n_layers=LAYERS).to(dev).eval()
     ctx = _native.get_context(local_rank)
 
-    # ---- workload: this rank's shard of DUTS-shaped region graphs (~600 regions each)
-    rng = np.random.default_rng(20_000 + rank)
-    host_graphs = [synthetic_region_graph(int(rng.integers(585, 618)), rng) for _ in range(args.batch)]
-    datas = [Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei), edge_attr=torch.from_numpy(ea))
-             for x, ei, ea in host_graphs]
-    batch = Batch.from_data_list(datas).to(dev)
-    n_nodes, n_edges = batch.x.size(0), batch.edge_index.size(1)
-    # pre-convert what the forward would otherwise convert per call (inputs resident in HBM)
-    batch.node_ptr32 = batch.ptr.to(torch.int32)
+    host_imgs = host_graphs = None
+    if args.workload == "full":
+        # this rank's shard: images rank*B .. rank*B + B - 1 of config 3 (seeds 30000 + index)
+        host_imgs = synthetic_batch(batch_size, H, W, config_id=3, first_index=rank * batch_size)
+        pipe = GCNGrabCutPipeline(model, sp_config=SuperpixelGraphConfig(n_segments=N_SEGMENTS), device=f"cuda:{local_rank}")
+        bgr = torch.from_numpy(host_imgs).to(dev)
+        last = {}
 
-    def step():
-        return model.predict_probs_device(batch)
+        def step():
+            last["out"] = pipe.segment_batch_device(bgr, compose=True)
+    else:
+        rng = np.random.default_rng(20_000 + rank)
+        host_graphs = [synthetic_region_graph(int(rng.integers(585, 618)), rng) for _ in range(batch_size)]
+        batch = Batch.from_data_list([Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei),
+                                           edge_attr=torch.from_numpy(ea)) for x, ei, ea in host_graphs]).to(dev)
+        batch.node_ptr32 = batch.ptr.to(torch.int32)
+        last = {}
+
+        def step():
+            last["out"] = model.predict_probs_device(batch)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -133,8 +152,10 @@ def main() -> None:
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    launches, agg_ms = ctx.profile_query("gcn_aggregate")
-    gemm_launches, gemm_ms = ctx.profile_query("gcn_gemm")
+    prof = {k: ctx.profile_query(k) for k in ("gcn_aggregate", "gcn_gemm", "slic_assign", "slic_update",
+                                               "slic_connectivity", "graph_stats", "graph_knn", "graph_prior",
+                                               "refine_trimap", "grabcut_init_gmm", "grabcut_gmm",
+                                               "maxflow_relabel", "maxflow_push")}
     ctx.profile_enable(False)
 
     if world > 1:
@@ -142,45 +163,81 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    images = args.batch * world * args.steps
+    images = batch_size * world * args.steps
     value = images / elapsed
 
-    out = None
     if rank == 0:
+        if args.workload == "full":
+            g = last["out"]["graphs"]
+            n_nodes, n_edges = int(g.node_ptr_host[-1]), int(g.edge_ptr_host[-1])
+        else:
+            n_nodes, n_edges = batch.x.size(0), batch.edge_index.size(1)
+        launches, agg_ms = prof["gcn_aggregate"]
         agg_avg_s = agg_ms / 1e3 / max(launches, 1)
-        b_launch = agg_bytes(n_nodes, n_edges, HIDDEN, args.batch)
+        b_launch = agg_bytes(n_nodes, n_edges, HIDDEN, batch_size)
         achieved = b_launch / agg_avg_s / 1e9 if launches else 0.0
         roofline = {
             "kernel": "k_aggregate<128,0> (GCNConv scatter-gather, fused gate/GELU/residual epilogue)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "bytes_per_launch": b_launch, "avg_launch_us": round(agg_avg_s * 1e6, 2), "launches": launches,
-            "gemm_avg_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
         }
-        cpu = None
+        stage_ms = {k: round(v[1] / args.steps, 3) for k, v in prof.items() if v[0]}
+
+        cpu = parity = None
         if args.cpu_sample > 0:
             from oracle import oracle as orc       # checker / CPU baseline only
             sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
-            sample = host_graphs[: args.cpu_sample]
-            orc.resgcn_forward(sd, HIDDEN, LAYERS, *sample[0])          # warm
-            t1 = time.perf_counter()
-            for x, ei, ea in sample:
-                orc.resgcn_forward(sd, HIDDEN, LAYERS, x, ei, ea)
-            dt = time.perf_counter() - t1
-            cpu = {"value": round(len(sample) / dt, 2), "unit": "images/s", "cores": 1, "kind": "port",
-                   "sample": f"{len(sample)} of the {args.batch} graphs, GCN forward only, C oracle (1 thread), "
-                             f"host has {len(os.sched_getaffinity(0))} cores"}
-        out = {
-            "metric": "images/sec end-to-end mask (DUTS-shape batch)", "value": round(value, 1),
+            n_s = min(args.cpu_sample, batch_size)
+            if args.workload == "full":
+                out = last["out"]
+                seg_g, tri_g = out["segments"][:n_s].cpu().numpy(), out["trimap"][:n_s].cpu().numpy()
+                bin_g, probs_g = out["binary_mask"][:n_s].cpu().numpy(), out["probs"].cpu().numpy()
+                t1 = time.perf_counter()
+                ref = [orc.segment(host_imgs[i], sd, HIDDEN, LAYERS, n_segments=N_SEGMENTS, seed=i) for i in range(n_s)]
+                dt = time.perf_counter() - t1
+                ious, dl = [], 0.0
+                for i, r in enumerate(ref):
+                    n0, n1 = int(g.node_ptr_host[i]), int(g.node_ptr_host[i + 1])
+                    if n1 - n0 == r["probs"].shape[0]:
+                        dl = max(dl, float(np.abs(probs_g[n0:n1] - r["probs"]).max()))
+                    ious.append(orc.iou(bin_g[i], r["binary_mask"]) if r["binary_mask"].any() or bin_g[i].any() else 1.0)
+                parity = {
+                    "sample": n_s,
+                    "label_map_exact_pct": round(100.0 * float(np.mean([np.array_equal(seg_g[i], ref[i]["segments"]) for i in range(n_s)])), 2),
+                    "trimap_pixel_match_pct": round(100.0 * float(np.mean([(tri_g[i] == ref[i]["trimap"]).mean() for i in range(n_s)])), 4),
+                    "mask_exact_pct": round(100.0 * float(np.mean([np.array_equal(bin_g[i], ref[i]["binary_mask"]) for i in range(n_s)])), 2),
+                    "max_abs_dprob": dl, "mean_mask_iou": round(float(np.mean(ious)), 6), "min_mask_iou": round(float(np.min(ious)), 6),
+                }
+                what = f"{n_s} of the {batch_size} images, full pipeline"
+            else:
+                probs_g = last["out"].cpu().numpy()
+                off = np.cumsum([0] + [x.shape[0] for x, _, _ in host_graphs])
+                orc.resgcn_forward(sd, HIDDEN, LAYERS, *host_graphs[0])          # warm
+                t1 = time.perf_counter()
+                ref = [orc.resgcn_forward(sd, HIDDEN, LAYERS, x, ei, ea) for x, ei, ea in host_graphs[:n_s]]
+                dt = time.perf_counter() - t1
+                parity = {"sample": n_s, "max_abs_dprob": max(float(np.abs(probs_g[off[i]:off[i + 1]] - ref[i][1]).max())
+                                                              for i in range(n_s))}
+                what = f"{n_s} of the {batch_size} graphs, GCN forward only"
+            cpu = {"value": round(n_s / dt, 3), "unit": "images/s", "cores": 1, "kind": "port",
+                   "sample": f"{what}; C oracle, 1 thread; host has {len(os.sched_getaffinity(0))} cores"}
+
+        cfg_name = ("configs[2]: full pipeline (SLIC->graph->ResGCNNet->guided-filter trimap->GrabCut 5 it->clean-up), "
+                    f"batch {batch_size} of {W}x{H}, n_segments={N_SEGMENTS}") if args.workload == "full" else \
+                   (f"configs[1]: batch {batch_size} DUTS-shape region graphs (~600 superpixels), "
+                    "ResGCNNet(D=128,n=6) forward only")
+        out_json = {
+            "metric": "images/sec end-to-end mask (DUTS-shape batch)", "value": round(value, 2),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: batch {args.batch} DUTS-shape region graphs (~600 superpixels), "
-                                   "ResGCNNet(D=128,n=6) forward only", "images_per_gpu": args.batch,
-                       "nodes": n_nodes, "directed_edges": n_edges, "weights": "seeded random init (seed 0)"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "config": {"workload": cfg_name, "images_per_gpu": batch_size, "nodes": n_nodes,
+                       "directed_edges": n_edges, "weights": "seeded random init (torch.manual_seed(0))"},
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity,
+            "stage_ms_per_step": stage_ms,
         }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out_json), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
