@@ -449,50 +449,91 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
 // ------------------------------------------------------------------ max-flow
 __device__ __forceinline__ int ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// start of a global relabel: d = 1 next to the sink, infinity elsewhere; rmask bit dir = residual arc p -> nb(dir)
 __global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __restrict__ done, const int32_t* __restrict__ snk,
-                                                  int32_t* __restrict__ dist) {
+                                                  const int32_t* __restrict__ rc, int32_t* __restrict__ dist,
+                                                  uint8_t* __restrict__ rmask) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)d.B * d.P || done[i / d.P]) return;
+    const size_t BP = (size_t)d.B * d.P;
+    if (i >= BP || done[i / d.P]) return;
     dist[i] = snk[i] > 0 ? 1 : DINF;
+    int m = 0;
+#pragma unroll
+    for (int dir = 0; dir < 8; ++dir) m |= (rc[(size_t)dir * BP + i] > 0) ? (1 << dir) : 0;
+    rmask[i] = (uint8_t)m;
 }
 
-// global relabel: in-place min-plus relaxation towards exact BFS distances to the sink
-__global__ void __launch_bounds__(256) k_mf_relax(GcDims d, int inner, const int32_t* __restrict__ done,
-                                                  const int32_t* __restrict__ rc, const int32_t* __restrict__ snk,
-                                                  int32_t* __restrict__ dist, int32_t* __restrict__ changed) {
+// Global relabel, tile-resident: a 32x32 pixel tile plus a one-pixel halo of distance labels lives in
+// LDS; the block relaxes d(u) = min(d(u), d(v) + 1 over residual arcs u -> v) in place until the tile
+// is stable (halo fixed), then writes back.  Launches repeat until no tile changes, so the number of
+// launches is the BFS depth measured in tiles rather than in pixels.
+constexpr int RT = 32;
+__global__ void __launch_bounds__(256) k_mf_relax_tile(GcDims d, const int32_t* __restrict__ done,
+                                                       const uint8_t* __restrict__ rmask, int32_t* __restrict__ dist,
+                                                       int32_t* __restrict__ changed) {
+    __shared__ int sd[RT + 2][RT + 2];
     const int b = blockIdx.z;
     if (done[b]) return;
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    const bool inb = x < d.W && y < d.H;
-    const size_t BP = (size_t)d.B * d.P, base = (size_t)b * d.P;
-    const int p = y * d.W + x;
-    int any = 0;
-    int cap[8], nbi[8];
-    bool fixed = true;
-    if (inb) {
-        fixed = snk[base + p] > 0;
-#pragma unroll
-        for (int dir = 0; dir < 8; ++dir) { nbi[dir] = dir_nb(d, y, x, dir); cap[dir] = rc[(size_t)dir * BP + base + p]; }
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * RT, ty0 = blockIdx.y * RT;
+    const size_t base = (size_t)b * d.P;
+    for (int i = tid; i < (RT + 2) * (RT + 2); i += 256) {
+        const int ly = i / (RT + 2), lx = i % (RT + 2);
+        const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+        sd[ly][lx] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
     }
-    for (int it = 0; it < inner; ++it) {
-        if (inb && !fixed) {
+    const int lx = tid & 31;
+    int msk[4], old[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ly = (tid >> 5) + 8 * j;
+        const int gy = ty0 + ly, gx = tx0 + lx;
+        msk[j] = (gx < d.W && gy < d.H) ? rmask[base + (size_t)gy * d.W + gx] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) old[j] = sd[(tid >> 5) + 8 * j + 1][lx + 1];
+    for (int it = 0; it < 4 * RT; ++it) {
+        int ch = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!msk[j]) continue;
+            const int ly = (tid >> 5) + 8 * j + 1, cx = lx + 1;
             int nd = DINF;
-#pragma unroll
-            for (int dir = 0; dir < 8; ++dir)
-                if (nbi[dir] >= 0 && cap[dir] > 0) { const int dq = ld(&dist[base + nbi[dir]]); if (dq < DINF) nd = min(nd, dq + 1); }
-            if (nd < ld(&dist[base + p])) { __hip_atomic_store(&dist[base + p], nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); any = 1; }
+            if (msk[j] & 1) nd = min(nd, sd[ly][cx - 1]);
+            if (msk[j] & 2) nd = min(nd, sd[ly][cx + 1]);
+            if (msk[j] & 4) nd = min(nd, sd[ly - 1][cx]);
+            if (msk[j] & 8) nd = min(nd, sd[ly + 1][cx]);
+            if (msk[j] & 16) nd = min(nd, sd[ly - 1][cx - 1]);
+            if (msk[j] & 32) nd = min(nd, sd[ly + 1][cx + 1]);
+            if (msk[j] & 64) nd = min(nd, sd[ly - 1][cx + 1]);
+            if (msk[j] & 128) nd = min(nd, sd[ly + 1][cx - 1]);
+            if (nd < DINF && nd + 1 < sd[ly][cx]) { sd[ly][cx] = nd + 1; ch = 1; }
         }
-        __syncthreads();
+        if (!__syncthreads_or(ch)) break;
     }
-    if (any) atomicOr(&changed[b], 1);
+    int any = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ly = (tid >> 5) + 8 * j;
+        const int v = sd[ly + 1][lx + 1];
+        if (v != old[j]) { dist[base + (size_t)(ty0 + ly) * d.W + tx0 + lx] = v; any = 1; }
+    }
+    if (__syncthreads_or(any) && tid == 0) atomicOr(&changed[b], 1);
 }
 
 // lock-free push-relabel sweep(s): every active pixel pushes to its lowest residual neighbour or relabels
+// Activity is sparse after the first round (about 1 % of the pixels), so the grid is gated by a per-tile
+// flag: tact_in says whether the 32x8 tile held (or was handed) excess; tact_out collects the tiles that
+// must run in the next launch (own leftover excess, or a push into a neighbouring tile).
 __global__ void __launch_bounds__(256) k_mf_pr(GcDims d, int inner, const int32_t* __restrict__ done,
                                                int32_t* __restrict__ rc, int32_t* __restrict__ ex,
-                                               int32_t* __restrict__ snk, int32_t* __restrict__ dist) {
+                                               int32_t* __restrict__ snk, int32_t* __restrict__ dist,
+                                               const int32_t* __restrict__ tact_in, int32_t* __restrict__ tact_out) {
     const int b = blockIdx.z;
     if (done[b]) return;
+    const int tile = (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (!tact_in[tile]) return;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
     const bool inb = x < d.W && y < d.H;
     const size_t BP = (size_t)d.B * d.P, base = (size_t)b * d.P;
@@ -526,6 +567,8 @@ __global__ void __launch_bounds__(256) k_mf_pr(GcDims d, int inner, const int32_
                         atomicAdd(&rc[(size_t)(best ^ 1) * BP + base + nbi[best]], dl);
                         atomicSub(&ex[base + p], dl);
                         atomicAdd(&ex[base + nbi[best]], dl);
+                        const int qy = nbi[best] / d.W, qx = nbi[best] - qy * d.W;
+                        tact_out[(b * gridDim.y + (qy >> 3)) * gridDim.x + (qx >> 5)] = 1;
                     }
                 } else {
                     const int nd = (best >= 0 && hmin < DINF) ? hmin + 1 : DINF;
@@ -535,15 +578,20 @@ __global__ void __launch_bounds__(256) k_mf_pr(GcDims d, int inner, const int32_
         }
         __syncthreads();
     }
+    if (inb && ld(&ex[base + p]) > 0 && ld(&dist[base + p]) < d.P) tact_out[tile] = 1;
 }
 
 __global__ void __launch_bounds__(256) k_mf_active(GcDims d, const int32_t* __restrict__ done, const int32_t* __restrict__ ex,
-                                                   const int32_t* __restrict__ dist, int32_t* __restrict__ active) {
+                                                   const int32_t* __restrict__ dist, int32_t* __restrict__ active,
+                                                   int32_t* __restrict__ tact, int tiles_x, int tiles_y) {
     const int b = blockIdx.y;
     if (done[b]) return;
     int n = 0;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.P; p += gridDim.x * blockDim.x)
-        n += (ex[(size_t)b * d.P + p] > 0 && dist[(size_t)b * d.P + p] < DINF) ? 1 : 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.P; p += gridDim.x * blockDim.x) {
+        const bool a = ex[(size_t)b * d.P + p] > 0 && dist[(size_t)b * d.P + p] < DINF;
+        if (a) { const int y = p / d.W, x = p - y * d.W; tact[(b * tiles_y + (y >> 3)) * tiles_x + (x >> 5)] = 1; }
+        n += a ? 1 : 0;
+    }
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(&active[b], n);
 }
@@ -581,13 +629,18 @@ static int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std
 }
 
 static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
-                   int32_t* snk, int32_t* dist, int32_t* done, int32_t* flags /*[B] changed | [B] active | [1] n_open*/) {
+                   int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* done,
+                   int32_t* flags /*[B] changed | [B] active | [1] n_open*/) {
     const int B = d.B;
     const size_t BP = (size_t)B * d.P;
     int32_t* changed = flags;
     int32_t* active = flags + B;
     int32_t* n_open = flags + 2 * B;
     const dim3 tiles(cdiv(d.W, 32), cdiv(d.H, 8), B);
+    const size_t n_tiles = (size_t)tiles.x * tiles.y * B;
+    int32_t* tact_a = scratch_t<int32_t>(ctx, S_GC_M, n_tiles * 2);
+    if (!tact_a) return GGC_E_OOM;
+    int32_t* tact_b = tact_a + n_tiles;
     hipLaunchKernelGGL(k_copy_i32, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, done);
     std::vector<int32_t> host;
     const int max_rounds = 4096;
@@ -595,11 +648,12 @@ static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t*
         // ---- global relabel
         {
             ProfScope prof(ctx, st, "maxflow_relabel");
-            hipLaunchKernelGGL(k_mf_dinit, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, done, snk, dist);
+            hipLaunchKernelGGL(k_mf_dinit, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, done, snk, rc, dist, rmask);
+            const dim3 rtiles(cdiv(d.W, RT), cdiv(d.H, RT), B);
             for (int guard = 0; guard < 100000; ++guard) {
                 GGC_HIP(ctx, hipMemsetAsync(changed, 0, sizeof(int32_t) * B, st));
-                for (int rep = 0; rep < 4; ++rep)
-                    hipLaunchKernelGGL(k_mf_relax, tiles, dim3(256), 0, st, d, 8, done, rc, snk, dist, changed);
+                for (int rep = 0; rep < 2; ++rep)
+                    hipLaunchKernelGGL(k_mf_relax_tile, rtiles, dim3(256), 0, st, d, done, rmask, dist, changed);
                 GGC_LAUNCH_CHECK(ctx);
                 int rcode = read_i32(ctx, st, changed, B, host);
                 if (rcode) return rcode;
@@ -610,17 +664,32 @@ static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t*
         }
         // ---- who still has work?
         GGC_HIP(ctx, hipMemsetAsync(active, 0, sizeof(int32_t) * (B + 1), st));
-        hipLaunchKernelGGL(k_mf_active, dim3(std::min(cdiv(d.P, 256 * 4), 128), B), dim3(256), 0, st, d, done, ex, dist, active);
+        GGC_HIP(ctx, hipMemsetAsync(tact_a, 0, sizeof(int32_t) * n_tiles, st));
+        hipLaunchKernelGGL(k_mf_active, dim3(std::min(cdiv(d.P, 256 * 4), 128), B), dim3(256), 0, st, d, done, ex, dist, active,
+                           tact_a, (int)tiles.x, (int)tiles.y);
         hipLaunchKernelGGL(k_done_update, dim3(cdiv(B, 256)), dim3(256), 0, st, B, active, done, n_open);
         GGC_LAUNCH_CHECK(ctx);
         int rcode = read_i32(ctx, st, n_open, 1, host);
         if (rcode) return rcode;
+        if (std::getenv("GGC_MF_TRACE")) {   // diagnostics: active pixels / open images per round
+            const int open = host[0];
+            std::vector<int32_t> act;
+            if ((rcode = read_i32(ctx, st, active, B, act))) return rcode;
+            long long tot = 0;
+            for (int v : act) tot += v;
+            std::fprintf(stderr, "[ggc maxflow] round %d: open images %d, active pixels %lld\n", round, open, tot);
+            host[0] = open;
+        }
         if (host[0] == 0) return GGC_OK;
         // ---- push-relabel sweeps
         {
             ProfScope prof(ctx, st, "maxflow_push");
-            for (int l = 0; l < 8; ++l)
-                hipLaunchKernelGGL(k_mf_pr, tiles, dim3(256), 0, st, d, 8, done, rc, ex, snk, dist);
+            int32_t *cur = tact_a, *nxt = tact_b;
+            for (int l = 0; l < 16; ++l) {
+                GGC_HIP(ctx, hipMemsetAsync(nxt, 0, sizeof(int32_t) * n_tiles, st));
+                hipLaunchKernelGGL(k_mf_pr, tiles, dim3(256), 0, st, d, 8, done, rc, ex, snk, dist, cur, nxt);
+                std::swap(cur, nxt);
+            }
             GGC_LAUNCH_CHECK(ctx);
         }
     }
@@ -653,7 +722,8 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
     int32_t* nw = scratch_t<int32_t>(ctx, S_GC_E, BP * 4);
     int32_t* rc = scratch_t<int32_t>(ctx, S_GC_F, BP * 8);
     int32_t* ex = scratch_t<int32_t>(ctx, S_GC_G, BP * 3);
-    if (!small || !gmm || !acc || !comp || !nw || !rc || !ex) return GGC_E_OOM;
+    uint8_t* rmask = scratch_t<uint8_t>(ctx, S_GC_L, BP);
+    if (!small || !gmm || !acc || !comp || !nw || !rc || !ex || !rmask) return GGC_E_OOM;
     int32_t* snk = ex + BP;
     int32_t* dist = ex + 2 * BP;
     int32_t *f1 = small, *f2 = small + B, *state = small + 2 * B, *done = small + 3 * B, *mf_flags = small + 4 * B;
@@ -710,7 +780,7 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                 hipLaunchKernelGGL(k_build_graph, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk);
             }
             GGC_LAUNCH_CHECK(ctx);
-            int rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, done, mf_flags);
+            int rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, done, mf_flags);
             if (rcode) return rcode;
             hipLaunchKernelGGL(k_gc_relabel, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, state, dist, mask);
             GGC_LAUNCH_CHECK(ctx);

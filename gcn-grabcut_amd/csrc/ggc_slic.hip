@@ -311,6 +311,192 @@ __global__ void __launch_bounds__(64) k_connectivity_seq(int H, int W, const int
     n_nodes[b] = cur > 0 ? cur : 1;
 }
 
+// ------------------------------------------- connectivity enforcement, parallel
+// Same result as the raster scan above, restructured so that only the
+// order-dependent parts stay sequential (SURVEY hard part 1.iii):
+//   1. union-find CCL of the raw label map (4-connectivity); a component's root
+//      is its smallest pixel index = the pixel where the raster scan discovers it;
+//   2. components of >= max_size pixels: one lane replays the capped BFS from the
+//      root (exactly max_size pixels in queue order), the carved piece keeps the
+//      root, the remainder is re-labelled by another CCL round (host loop; real
+//      SLIC output needs zero or one extra round);
+//   3. components of >= min_size pixels keep their discovery rank (prefix sum over
+//      the roots in raster order) as their label;
+//   4. components of < min_size pixels: one lane replays the BFS and remembers the
+//      last neighbour pixel that belongs to an earlier-discovered component; the
+//      label is inherited along that pointer chain (0 when there is none).
+// Validated pixel-for-pixel against the sequential kernel and the CPU oracle.
+__device__ __forceinline__ int cn_find(const int32_t* parent, int i) {
+    int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != i) { i = p; p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return i;
+}
+__device__ __forceinline__ void cn_union(int32_t* parent, int a, int b) {
+    for (;;) {
+        a = cn_find(parent, a); b = cn_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+struct CnDims { int B, H, W, P, min_size, max_size; };
+
+__global__ void __launch_bounds__(256) k_cn_reset(CnDims d, const uint8_t* __restrict__ pending, int32_t* __restrict__ parent,
+                                                  int32_t* __restrict__ csize) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)d.B * d.P || !pending[i]) return;
+    parent[i] = (int)(i % d.P);
+    csize[i] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_cn_merge(CnDims d, const int32_t* __restrict__ raw, const uint8_t* __restrict__ pending,
+                                                  int32_t* __restrict__ parent) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= d.W || y >= d.H) return;
+    const size_t base = (size_t)blockIdx.z * d.P;
+    const int p = y * d.W + x;
+    if (!pending[base + p]) return;
+    const int l = raw[base + p];
+    if (x > 0 && pending[base + p - 1] && raw[base + p - 1] == l) cn_union(parent + base, p, p - 1);
+    if (y > 0 && pending[base + p - d.W] && raw[base + p - d.W] == l) cn_union(parent + base, p, p - d.W);
+}
+
+__global__ void __launch_bounds__(256) k_cn_size(CnDims d, const uint8_t* __restrict__ pending, int32_t* __restrict__ parent,
+                                                 int32_t* __restrict__ csize) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)d.B * d.P || !pending[i]) return;
+    const size_t base = (i / d.P) * d.P;
+    const int r = cn_find(parent + base, (int)(i - base));
+    parent[i] = r;
+    atomicAdd(&csize[base + r], 1);
+}
+
+// components below max_size are final; count the ones that still need carving
+__global__ void __launch_bounds__(256) k_cn_settle(CnDims d, uint8_t* __restrict__ pending, const int32_t* __restrict__ parent,
+                                                   const int32_t* __restrict__ csize, int32_t* __restrict__ n_big) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)d.B * d.P || !pending[i]) return;
+    const size_t base = (i / d.P) * d.P;
+    const int p = (int)(i - base), r = parent[i];
+    if (csize[base + r] < d.max_size) pending[i] = 0;
+    else if (p == r) atomicAdd(n_big, 1);
+}
+
+// replay of the capped BFS for every root of a too-large component (one lane each)
+__global__ void __launch_bounds__(64) k_cn_carve(CnDims d, int tag, uint8_t* __restrict__ pending, const int32_t* __restrict__ parent,
+                                                 int32_t* __restrict__ csize, int32_t* __restrict__ mark,
+                                                 int32_t* __restrict__ queue, int32_t* __restrict__ qtop) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)d.B * d.P) return;
+    const int b = (int)(i / d.P);
+    const size_t base = (size_t)b * d.P;
+    const int r = (int)(i - base);
+    if (!pending[i] || parent[i] != r || csize[i] < d.max_size) return;
+    int32_t* q = queue + base + atomicAdd(&qtop[b], d.max_size);
+    int size = 1, visited = 0;
+    q[0] = r; mark[base + r] = tag;
+    while (visited < size && size < d.max_size) {
+        const int pc = q[visited];
+        const int yc = pc / d.W, xc = pc - yc * d.W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = xc + (k == 0 ? 1 : k == 1 ? -1 : 0), yy = yc + (k == 2 ? 1 : k == 3 ? -1 : 0);
+            if (xx < 0 || xx >= d.W || yy < 0 || yy >= d.H) continue;
+            const int pp = yy * d.W + xx;
+            if (pending[base + pp] && parent[base + pp] == r && mark[base + pp] != tag) {
+                mark[base + pp] = tag;
+                q[size++] = pp;
+                if (size >= d.max_size) break;
+            }
+        }
+        visited += 1;
+    }
+    for (int k = 0; k < size; ++k) pending[base + q[k]] = 0;   // the carved piece is final, root r
+    csize[i] = size;
+}
+
+// kept flag at the roots (1 = keeps its own label), everything else 0; scanned per image afterwards
+__global__ void __launch_bounds__(256) k_cn_kept(CnDims d, const int32_t* __restrict__ parent, const int32_t* __restrict__ csize,
+                                                 int32_t* __restrict__ rank) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)d.B * d.P) return;
+    rank[i] = (parent[i] == (int)(i % d.P) && csize[i] >= d.min_size) ? 1 : 0;
+}
+
+// per-image exclusive scan (block per image); n_nodes = max(total, 1)
+__global__ void __launch_bounds__(1024) k_cn_scan(CnDims d, int32_t* __restrict__ rank, int32_t* __restrict__ n_nodes) {
+    __shared__ int32_t part[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int32_t* a = rank + (size_t)b * d.P;
+    const int chunk = (d.P + 1023) / 1024;
+    const int beg = min(tid * chunk, d.P), end = min(beg + chunk, d.P);
+    int32_t s = 0;
+    for (int i = beg; i < end; ++i) s += a[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int32_t run = tid ? part[tid - 1] : 0;
+    for (int i = beg; i < end; ++i) { const int32_t c = a[i]; a[i] = run; run += c; }
+    if (tid == 1023) n_nodes[b] = part[1023] > 0 ? part[1023] : 1;
+}
+
+// small components: replay the BFS, remember the last neighbour of an earlier component
+__global__ void __launch_bounds__(64) k_cn_small(CnDims d, int tag, const int32_t* __restrict__ parent,
+                                                 const int32_t* __restrict__ csize, int32_t* __restrict__ mark,
+                                                 int32_t* __restrict__ queue, int32_t* __restrict__ qtop,
+                                                 int32_t* __restrict__ tgt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)d.B * d.P) return;
+    const int b = (int)(i / d.P);
+    const size_t base = (size_t)b * d.P;
+    const int r = (int)(i - base);
+    if (parent[i] != r || csize[i] >= d.min_size) return;
+    const int n = csize[i];
+    int32_t* q = queue + base + atomicAdd(&qtop[b], n);
+    int size = 1, visited = 0, last = -1;
+    q[0] = r; mark[base + r] = tag;
+    while (visited < size) {
+        const int pc = q[visited];
+        const int yc = pc / d.W, xc = pc - yc * d.W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = xc + (k == 0 ? 1 : k == 1 ? -1 : 0), yy = yc + (k == 2 ? 1 : k == 3 ? -1 : 0);
+            if (xx < 0 || xx >= d.W || yy < 0 || yy >= d.H) continue;
+            const int pp = yy * d.W + xx;
+            const int rp = parent[base + pp];
+            if (rp == r) { if (mark[base + pp] != tag && size < n) { mark[base + pp] = tag; q[size++] = pp; } }
+            else if (rp < r) last = rp;      // discovered earlier => already labelled when the scan gets here
+        }
+        visited += 1;
+    }
+    tgt[i] = last;
+}
+
+__global__ void __launch_bounds__(256) k_cn_write(CnDims d, const int32_t* __restrict__ parent, const int32_t* __restrict__ csize,
+                                                  const int32_t* __restrict__ rank, const int32_t* __restrict__ tgt,
+                                                  int32_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)d.B * d.P) return;
+    const size_t base = (i / d.P) * d.P;
+    int r = parent[i];
+    int lab = 0;
+    for (;;) {
+        if (csize[base + r] >= d.min_size) { lab = rank[base + r]; break; }
+        const int t = tgt[base + r];
+        if (t < 0) { lab = 0; break; }
+        r = t;
+    }
+    out[i] = lab;
+}
+
 // ------------------------------------------------------------- host helpers
 
 // numpy's pairwise summation for n <= 128 (scipy normalises the kernel with ndarray.sum())
@@ -357,6 +543,57 @@ static Grid regular_grid(int H, int W, int n_points) {
 } // namespace ggc
 
 using namespace ggc;
+
+static int enforce_connectivity(ggc_ctx* ctx, hipStream_t st, int B, int H, int W, const int32_t* raw, int min_size,
+                                int max_size, int32_t* segments, int32_t* n_nodes) {
+    const size_t P = (size_t)H * W;
+    if (std::getenv("GGC_SLIC_SEQ_CONNECTIVITY")) {   // literal raster-scan replay, one thread per image (A/B reference)
+        int32_t* queue = scratch_t<int32_t>(ctx, S_SLIC_AUX3, (size_t)B * (size_t)std::max(max_size, 1));
+        if (!queue) return GGC_E_OOM;
+        GGC_HIP(ctx, hipMemsetAsync(segments, 0xFF, sizeof(int32_t) * (size_t)B * P, st));
+        ProfScope prof(ctx, st, "slic_connectivity");
+        hipLaunchKernelGGL(k_connectivity_seq, dim3(B), dim3(64), 0, st, H, W, raw, min_size, max_size, queue, segments,
+                           n_nodes);
+        GGC_LAUNCH_CHECK(ctx);
+        return GGC_OK;
+    }
+    {
+        ProfScope prof(ctx, st, "slic_connectivity");
+        const size_t BP = (size_t)B * P;
+        const CnDims cd{B, H, W, (int)P, min_size, std::max(max_size, 1)};
+        int32_t* work = scratch_t<int32_t>(ctx, S_SLIC_AUX3, BP * 6 + (size_t)B * (size_t)cd.max_size + 2 * (size_t)B + 16);
+        uint8_t* pending = scratch_t<uint8_t>(ctx, S_SLIC_AUX4, BP);
+        if (!work || !pending) return GGC_E_OOM;
+        int32_t *parent = work, *csize = work + BP, *rank = work + 2 * BP, *tgt = work + 3 * BP, *mark = work + 4 * BP;
+        int32_t* queue = work + 5 * BP;                       // per image P (+ max_size slack at the very end)
+        int32_t* qtop = work + 6 * BP + (size_t)B * cd.max_size;
+        int32_t* n_big = qtop + B;
+        GGC_HIP(ctx, hipMemsetAsync(pending, 1, BP, st));
+        GGC_HIP(ctx, hipMemsetAsync(mark, 0, sizeof(int32_t) * BP, st));
+        const dim3 g1(cdiv(BP, 256)), g2(cdiv(W, 64), cdiv(H, 4), B), g64(cdiv(BP, 64));
+        for (int round = 0; round < 4096; ++round) {
+            GGC_HIP(ctx, hipMemsetAsync(qtop, 0, sizeof(int32_t) * (B + 1), st));
+            hipLaunchKernelGGL(k_cn_reset, g1, dim3(256), 0, st, cd, pending, parent, csize);
+            hipLaunchKernelGGL(k_cn_merge, g2, dim3(256), 0, st, cd, raw, pending, parent);
+            hipLaunchKernelGGL(k_cn_size, g1, dim3(256), 0, st, cd, pending, parent, csize);
+            hipLaunchKernelGGL(k_cn_settle, g1, dim3(256), 0, st, cd, pending, parent, csize, n_big);
+            GGC_LAUNCH_CHECK(ctx);
+            int32_t h_big = 0;
+            GGC_HIP(ctx, hipMemcpyAsync(&h_big, n_big, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            GGC_HIP(ctx, hipStreamSynchronize(st));
+            if (h_big == 0) break;
+            hipLaunchKernelGGL(k_cn_carve, g64, dim3(64), 0, st, cd, round + 1, pending, parent, csize, mark, queue, qtop);
+            GGC_LAUNCH_CHECK(ctx);
+        }
+        hipLaunchKernelGGL(k_cn_kept, g1, dim3(256), 0, st, cd, parent, csize, rank);
+        hipLaunchKernelGGL(k_cn_scan, dim3(B), dim3(1024), 0, st, cd, rank, n_nodes);
+        GGC_HIP(ctx, hipMemsetAsync(qtop, 0, sizeof(int32_t) * (B + 1), st));
+        hipLaunchKernelGGL(k_cn_small, g64, dim3(64), 0, st, cd, 0x7FFFFFFF, parent, csize, mark, queue, qtop, tgt);
+        hipLaunchKernelGGL(k_cn_write, g1, dim3(256), 0, st, cd, parent, csize, rank, tgt, segments);
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    return GGC_OK;
+}
 
 extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, const float* image,
                         int n_segments, float compactness, float sigma, int rescale_input,
@@ -437,14 +674,18 @@ extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, co
     // 7: connectivity
     const double seg_size = (double)P / (double)g.K;
     const int min_size = (int)(0.5 * seg_size), max_size = (int)(3.0 * seg_size);
-    int32_t* queue = scratch_t<int32_t>(ctx, S_SLIC_AUX3, (size_t)B * (size_t)std::max(max_size, 1));
-    if (!queue) return GGC_E_OOM;
-    GGC_HIP(ctx, hipMemsetAsync(segments, 0xFF, sizeof(int32_t) * (size_t)B * P, st));
-    {
-        ProfScope prof(ctx, st, "slic_connectivity");
-        hipLaunchKernelGGL(k_connectivity_seq, dim3(B), dim3(64), 0, st, H, W, raw, min_size, max_size, queue, segments,
-                           n_nodes);
-    }
-    GGC_LAUNCH_CHECK(ctx);
-    return GGC_OK;
+    return enforce_connectivity(ctx, st, B, H, W, raw, min_size, max_size, segments, n_nodes);
+}
+
+// Step 7 alone (skimage's _enforce_label_connectivity_cython) — exposed so the parity
+// tests can drive the carve / merge paths with hand-made label maps.
+extern "C" int ggc_slic_enforce_connectivity(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
+                                             const int32_t* raw_labels, int min_size, int max_size,
+                                             int32_t* segments, int32_t* n_nodes) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, B >= 1 && H >= 1 && W >= 1 && B <= 65535, GGC_E_SHAPE, "bad shape B=%d H=%d W=%d", B, H, W);
+    GGC_REQUIRE(ctx, raw_labels && segments && n_nodes && min_size >= 0 && max_size >= 0, GGC_E_INVALID_ARG, "bad arguments");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    return enforce_connectivity(ctx, reinterpret_cast<hipStream_t>(stream), B, H, W, raw_labels, min_size, max_size,
+                                segments, n_nodes);
 }

@@ -101,6 +101,13 @@ int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
              const float* image, int n_segments, float compactness, float sigma,
              int rescale_input, int32_t* segments, int32_t* n_nodes);
 
+/* Step 7 of ggc_slic alone — skimage's _enforce_label_connectivity_cython
+ * (SURVEY Appendix A.1): raw_labels, segments [dev] i32 [B,H,W]; n_nodes [dev] i32 [B].
+ * SYNCHRONISES the stream once per carve round (components of >= max_size pixels). */
+int ggc_slic_enforce_connectivity(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
+                                  const int32_t* raw_labels, int min_size, int max_size,
+                                  int32_t* segments, int32_t* n_nodes);
+
 /* ------------------------------------------------------------ G2-G8 graph build
  * Replaces GraphBuilder.build's tail (graph_builder.py:160-175):
  * _region_statistics, _assemble_node_features, _compute_edges (+_pair_features,

@@ -117,3 +117,46 @@ def test_slic_constant_image(oracle, gpu_ctx):
     got, gn = _slic(gpu_ctx, lab, 30)
     want, wn = oracle.slic(lab.cpu().numpy()[0], 30, 10.0, 1.0, True)
     assert np.array_equal(got[0], want) and gn[0] == wn
+
+
+def _connectivity(gpu_ctx, raw, mn, mx):
+    from gcn_grabcut import _native
+    b, h, w = raw.shape
+    d = torch.as_tensor(np.ascontiguousarray(raw, dtype=np.int32)).cuda()
+    out = torch.empty_like(d)
+    n = torch.empty(b, dtype=torch.int32, device="cuda")
+    gpu_ctx.call("ggc_slic_enforce_connectivity", _native.current_stream(0), b, h, w, d.data_ptr(), int(mn), int(mx),
+                 out.data_ptr(), n.data_ptr())
+    return out.cpu().numpy(), n.cpu().numpy()
+
+
+@pytest.mark.parametrize("tag,mn,mx", [("a", 4, 200), ("b", 12, 60), ("c", 1, 10 ** 6)])
+def test_connectivity_stress_vs_skimage_golden(gpu_ctx, tag, mn, mx):
+    """components far above max_size (many carve rounds) and many tiny fragments (merge chains)"""
+    got, n = _connectivity(gpu_ctx, GOLD["stress_in"][None], mn, mx)
+    assert np.array_equal(got[0], GOLD[f"stress_{tag}"])
+    assert n[0] == GOLD[f"stress_{tag}"].max() + 1
+
+
+def test_connectivity_random_label_maps_batch(oracle, gpu_ctx):
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        h, w, b = int(rng.integers(9, 70)), int(rng.integers(9, 90)), 5
+        k = int(rng.integers(2, 7))
+        raw = rng.integers(0, k, (b, h, w)).astype(np.int32)
+        raw[1] = np.kron(rng.integers(0, k, ((h + 4) // 5, (w + 4) // 5)), np.ones((5, 5), int))[:h, :w]
+        raw[2] = 0                                                     # one giant component
+        raw[3, ::2] = 1; raw[3, 1::2] = 0                              # stripes
+        mn = int(rng.integers(0, 15)); mx = int(rng.integers(max(mn, 1), 120))
+        got, n = _connectivity(gpu_ctx, raw, mn, mx)
+        for i in range(b):
+            want, wn = oracle.slic_connectivity(raw[i], mn, mx)
+            assert np.array_equal(got[i], want), (trial, i, h, w, mn, mx, int((got[i] != want).sum()))
+            assert n[i] == wn
+
+
+def test_connectivity_matches_on_real_kmeans_output(oracle, gpu_ctx):
+    for i in range(5):
+        raw = GOLD[f"c{i}_raw"]
+        got, n = _connectivity(gpu_ctx, raw[None], int(GOLD[f"c{i}_min_size"]), int(GOLD[f"c{i}_max_size"]))
+        assert np.array_equal(got[0], GOLD[f"c{i}_connected"])
