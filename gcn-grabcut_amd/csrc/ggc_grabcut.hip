@@ -470,10 +470,14 @@ __global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __res
 constexpr int RT = 32;
 __global__ void __launch_bounds__(256) k_mf_relax_tile(GcDims d, const int32_t* __restrict__ done,
                                                        const uint8_t* __restrict__ rmask, int32_t* __restrict__ dist,
-                                                       int32_t* __restrict__ changed) {
+                                                       int32_t* __restrict__ changed,
+                                                       const int32_t* __restrict__ front_in, int32_t* __restrict__ front_out) {
     __shared__ int sd[RT + 2][RT + 2];
     const int b = blockIdx.z;
     if (done[b]) return;
+    // frontier gating: a tile only needs another pass if it or one of its 8 neighbours changed last time
+    const int tile = (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (!front_in[tile]) return;
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * RT, ty0 = blockIdx.y * RT;
     const size_t base = (size_t)b * d.P;
@@ -519,7 +523,12 @@ __global__ void __launch_bounds__(256) k_mf_relax_tile(GcDims d, const int32_t* 
         const int v = sd[ly + 1][lx + 1];
         if (v != old[j]) { dist[base + (size_t)(ty0 + ly) * d.W + tx0 + lx] = v; any = 1; }
     }
-    if (__syncthreads_or(any) && tid == 0) atomicOr(&changed[b], 1);
+    if (__syncthreads_or(any) && tid < 9) {
+        if (tid == 0) atomicOr(&changed[b], 1);
+        const int ty = (int)blockIdx.y + tid / 3 - 1, tx = (int)blockIdx.x + tid % 3 - 1;
+        if (ty >= 0 && ty < (int)gridDim.y && tx >= 0 && tx < (int)gridDim.x)
+            front_out[(b * gridDim.y + ty) * gridDim.x + tx] = 1;
+    }
 }
 
 // lock-free push-relabel sweep(s): every active pixel pushes to its lowest residual neighbour or relabels
@@ -579,6 +588,104 @@ __global__ void __launch_bounds__(256) k_mf_pr(GcDims d, int inner, const int32_
         __syncthreads();
     }
     if (inb && ld(&ex[base + p]) > 0 && ld(&dist[base + p]) < d.P) tact_out[tile] = 1;
+}
+
+// Tile-resident form of the sweep above: a 32x8 tile's excess, residual capacities and labels (plus a
+// one-pixel halo of labels) live in LDS for `inner` iterations, so an iteration costs LDS traffic only.
+// Pushes that stay inside the tile use LDS atomics; pushes across the tile edge go straight to global
+// memory with atomics.  Because a neighbouring tile may add to this tile's global excess / reverse
+// capacities while it runs, the write-back applies DELTAS atomically instead of storing values.  Every
+// value read stale is a lower bound of the true one (others only add excess / capacity and labels only
+// grow), which is exactly the asynchrony the lock-free algorithm tolerates.
+__global__ void __launch_bounds__(256) k_mf_pr_tile(GcDims d, int inner, const int32_t* __restrict__ done,
+                                                    int32_t* __restrict__ rc, int32_t* __restrict__ ex,
+                                                    int32_t* __restrict__ snk, int32_t* __restrict__ dist,
+                                                    const int32_t* __restrict__ tact_in, int32_t* __restrict__ tact_out) {
+    __shared__ int s_ex[256];
+    __shared__ int s_d[10][34];
+    __shared__ int s_rc[8][256];
+    const int b = blockIdx.z;
+    if (done[b]) return;
+    const int tile = (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (!tact_in[tile]) return;
+    const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
+    const int x = blockIdx.x * 32 + lx, y = blockIdx.y * 8 + ly;
+    const bool inb = x < d.W && y < d.H;
+    const size_t BP = (size_t)d.B * d.P, base = (size_t)b * d.P;
+    const int p = y * d.W + x;
+    int e0 = 0, sk0 = 0, r0[8];
+    if (inb) { e0 = ex[base + p]; sk0 = snk[base + p]; }
+    s_ex[tid] = e0;
+#pragma unroll
+    for (int dir = 0; dir < 8; ++dir) { r0[dir] = inb ? rc[(size_t)dir * BP + base + p] : 0; s_rc[dir][tid] = r0[dir]; }
+    for (int i = tid; i < 10 * 34; i += 256) {
+        const int gy = blockIdx.y * 8 + i / 34 - 1, gx = blockIdx.x * 32 + i % 34 - 1;
+        s_d[i / 34][i % 34] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
+    }
+    __syncthreads();
+    const int d0 = s_d[ly + 1][lx + 1];
+    int sk = sk0;
+    // direction -> offset as arithmetic (a runtime-indexed table would live in scratch memory)
+    auto ddx = [](int dir) { return (dir == 0 || dir == 4 || dir == 7) ? -1 : ((dir == 1 || dir == 5 || dir == 6) ? 1 : 0); };
+    auto ddy = [](int dir) { return (dir == 2 || dir == 4 || dir == 6) ? -1 : ((dir == 3 || dir == 5 || dir == 7) ? 1 : 0); };
+    for (int it = 0; it < inner; ++it) {
+        int act = 0;
+        if (inb) {
+            const int e = __hip_atomic_load(&s_ex[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int dp = s_d[ly + 1][lx + 1];
+            if (e > 0 && dp < d.P) {
+                act = 1;
+                int hmin = DINF, best = -1;
+                if (sk > 0) { hmin = 0; best = 8; }
+#pragma unroll
+                for (int dir = 0; dir < 8; ++dir)
+                    if (__hip_atomic_load(&s_rc[dir][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) {
+                        const int hq = s_d[ly + 1 + ddy(dir)][lx + 1 + ddx(dir)];
+                        if (hq < hmin) { hmin = hq; best = dir; }
+                    }
+                if (best >= 0 && dp > hmin) {
+                    if (best == 8) {
+                        const int dl = min(e, sk);
+                        sk -= dl;
+                        atomicSub(&s_ex[tid], dl);
+                    } else {
+                        const int dl = min(e, __hip_atomic_load(&s_rc[best][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        atomicSub(&s_rc[best][tid], dl);
+                        atomicSub(&s_ex[tid], dl);
+                        const int bx = ddx(best), by = ddy(best);
+                        const int qlx = lx + bx, qly = ly + by;
+                        if (qlx >= 0 && qlx < 32 && qly >= 0 && qly < 8) {
+                            const int qt = qly * 32 + qlx;
+                            atomicAdd(&s_rc[best ^ 1][qt], dl);
+                            atomicAdd(&s_ex[qt], dl);
+                        } else {
+                            const int q = p + by * d.W + bx;
+                            atomicAdd(&rc[(size_t)(best ^ 1) * BP + base + q], dl);
+                            atomicAdd(&ex[base + q], dl);
+                            const int qy = y + by, qx = x + bx;
+                            tact_out[(b * gridDim.y + (qy >> 3)) * gridDim.x + (qx >> 5)] = 1;
+                        }
+                    }
+                } else {
+                    s_d[ly + 1][lx + 1] = (best >= 0 && hmin < DINF) ? hmin + 1 : DINF;
+                }
+            }
+        }
+        if (!__syncthreads_or(act)) break;
+    }
+    if (inb) {
+        const int e1 = s_ex[tid];
+        if (e1 != e0) atomicAdd(&ex[base + p], e1 - e0);
+#pragma unroll
+        for (int dir = 0; dir < 8; ++dir) {
+            const int r1 = s_rc[dir][tid];
+            if (r1 != r0[dir]) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[dir]);
+        }
+        if (sk != sk0) snk[base + p] = sk;
+        const int d1 = s_d[ly + 1][lx + 1];
+        if (d1 != d0) dist[base + p] = d1;
+        if (e1 > 0 && d1 < d.P) tact_out[tile] = 1;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_mf_active(GcDims d, const int32_t* __restrict__ done, const int32_t* __restrict__ ex,
@@ -641,6 +748,8 @@ static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t*
     int32_t* tact_a = scratch_t<int32_t>(ctx, S_GC_M, n_tiles * 2);
     if (!tact_a) return GGC_E_OOM;
     int32_t* tact_b = tact_a + n_tiles;
+    int32_t* front_a = scratch_t<int32_t>(ctx, S_GC_N, (size_t)cdiv(d.W, RT) * cdiv(d.H, RT) * B * 2);
+    if (!front_a) return GGC_E_OOM;
     hipLaunchKernelGGL(k_copy_i32, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, done);
     std::vector<int32_t> host;
     const int max_rounds = 4096;
@@ -650,10 +759,16 @@ static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t*
             ProfScope prof(ctx, st, "maxflow_relabel");
             hipLaunchKernelGGL(k_mf_dinit, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, done, snk, rc, dist, rmask);
             const dim3 rtiles(cdiv(d.W, RT), cdiv(d.H, RT), B);
+            const size_t n_rt = (size_t)rtiles.x * rtiles.y * B;
+            int32_t *fr_cur = front_a, *fr_nxt = front_a + n_rt;
+            GGC_HIP(ctx, hipMemsetAsync(fr_cur, 1, sizeof(int32_t) * n_rt, st));     // every tile starts on the frontier
             for (int guard = 0; guard < 100000; ++guard) {
                 GGC_HIP(ctx, hipMemsetAsync(changed, 0, sizeof(int32_t) * B, st));
-                for (int rep = 0; rep < 2; ++rep)
-                    hipLaunchKernelGGL(k_mf_relax_tile, rtiles, dim3(256), 0, st, d, done, rmask, dist, changed);
+                for (int rep = 0; rep < 4; ++rep) {
+                    GGC_HIP(ctx, hipMemsetAsync(fr_nxt, 0, sizeof(int32_t) * n_rt, st));
+                    hipLaunchKernelGGL(k_mf_relax_tile, rtiles, dim3(256), 0, st, d, done, rmask, dist, changed, fr_cur, fr_nxt);
+                    std::swap(fr_cur, fr_nxt);
+                }
                 GGC_LAUNCH_CHECK(ctx);
                 int rcode = read_i32(ctx, st, changed, B, host);
                 if (rcode) return rcode;
@@ -687,7 +802,7 @@ static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t*
             int32_t *cur = tact_a, *nxt = tact_b;
             for (int l = 0; l < 16; ++l) {
                 GGC_HIP(ctx, hipMemsetAsync(nxt, 0, sizeof(int32_t) * n_tiles, st));
-                hipLaunchKernelGGL(k_mf_pr, tiles, dim3(256), 0, st, d, 8, done, rc, ex, snk, dist, cur, nxt);
+                hipLaunchKernelGGL(k_mf_pr_tile, tiles, dim3(256), 0, st, d, 16, done, rc, ex, snk, dist, cur, nxt);
                 std::swap(cur, nxt);
             }
             GGC_LAUNCH_CHECK(ctx);
