@@ -450,12 +450,15 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
 __device__ __forceinline__ int ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // start of a global relabel: d = 1 next to the sink, infinity elsewhere; rmask bit dir = residual arc p -> nb(dir)
-__global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __restrict__ done, const int32_t* __restrict__ snk,
+// All max-flow kernels run over the compacted list of images that still have active pixels
+// (open_list, grid z or y = number of open images): late rounds typically have 1-5 open images out of 256.
+__global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __restrict__ open_list, const int32_t* __restrict__ snk,
                                                   const int32_t* __restrict__ rc, int32_t* __restrict__ dist,
                                                   uint8_t* __restrict__ rmask) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t BP = (size_t)d.B * d.P;
-    if (i >= BP || done[i / d.P]) return;
+    if (p >= d.P) return;
+    const size_t i = (size_t)open_list[blockIdx.y] * d.P + p;
     dist[i] = snk[i] > 0 ? 1 : DINF;
     int m = 0;
 #pragma unroll
@@ -467,14 +470,15 @@ __global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __res
 // LDS; the block relaxes d(u) = min(d(u), d(v) + 1 over residual arcs u -> v) in place until the tile
 // is stable (halo fixed), then writes back.  Launches repeat until no tile changes, so the number of
 // launches is the BFS depth measured in tiles rather than in pixels.
-constexpr int RT = 32;
-__global__ void __launch_bounds__(256) k_mf_relax_tile(GcDims d, const int32_t* __restrict__ done,
+constexpr int RT = 32;                       // tile side (64 measured 2x slower: longer local fixpoints)
+constexpr int RT_ROWS = 256 / RT;            // tile rows covered by one pass of the 256 threads
+constexpr int RT_NJ = RT * RT / 256;         // pixels per thread
+__global__ void __launch_bounds__(256) k_mf_relax_tile(GcDims d, const int32_t* __restrict__ open_list,
                                                        const uint8_t* __restrict__ rmask, int32_t* __restrict__ dist,
                                                        int32_t* __restrict__ changed,
                                                        const int32_t* __restrict__ front_in, int32_t* __restrict__ front_out) {
     __shared__ int sd[RT + 2][RT + 2];
-    const int b = blockIdx.z;
-    if (done[b]) return;
+    const int b = open_list[blockIdx.z];
     // frontier gating: a tile only needs another pass if it or one of its 8 neighbours changed last time
     const int tile = (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (!front_in[tile]) return;
@@ -486,23 +490,23 @@ __global__ void __launch_bounds__(256) k_mf_relax_tile(GcDims d, const int32_t* 
         const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
         sd[ly][lx] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
     }
-    const int lx = tid & 31;
-    int msk[4], old[4];
+    const int lx = tid % RT;
+    int msk[RT_NJ], old[RT_NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ly = (tid >> 5) + 8 * j;
+    for (int j = 0; j < RT_NJ; ++j) {
+        const int ly = (tid / RT) + RT_ROWS * j;
         const int gy = ty0 + ly, gx = tx0 + lx;
         msk[j] = (gx < d.W && gy < d.H) ? rmask[base + (size_t)gy * d.W + gx] : 0;
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) old[j] = sd[(tid >> 5) + 8 * j + 1][lx + 1];
+    for (int j = 0; j < RT_NJ; ++j) old[j] = sd[(tid / RT) + RT_ROWS * j + 1][lx + 1];
     for (int it = 0; it < 4 * RT; ++it) {
         int ch = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RT_NJ; ++j) {
             if (!msk[j]) continue;
-            const int ly = (tid >> 5) + 8 * j + 1, cx = lx + 1;
+            const int ly = (tid / RT) + RT_ROWS * j + 1, cx = lx + 1;
             int nd = DINF;
             if (msk[j] & 1) nd = min(nd, sd[ly][cx - 1]);
             if (msk[j] & 2) nd = min(nd, sd[ly][cx + 1]);
@@ -518,8 +522,8 @@ __global__ void __launch_bounds__(256) k_mf_relax_tile(GcDims d, const int32_t* 
     }
     int any = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ly = (tid >> 5) + 8 * j;
+    for (int j = 0; j < RT_NJ; ++j) {
+        const int ly = (tid / RT) + RT_ROWS * j;
         const int v = sd[ly + 1][lx + 1];
         if (v != old[j]) { dist[base + (size_t)(ty0 + ly) * d.W + tx0 + lx] = v; any = 1; }
     }
@@ -597,15 +601,14 @@ __global__ void __launch_bounds__(256) k_mf_pr(GcDims d, int inner, const int32_
 // capacities while it runs, the write-back applies DELTAS atomically instead of storing values.  Every
 // value read stale is a lower bound of the true one (others only add excess / capacity and labels only
 // grow), which is exactly the asynchrony the lock-free algorithm tolerates.
-__global__ void __launch_bounds__(256) k_mf_pr_tile(GcDims d, int inner, const int32_t* __restrict__ done,
+__global__ void __launch_bounds__(256) k_mf_pr_tile(GcDims d, int inner, const int32_t* __restrict__ open_list,
                                                     int32_t* __restrict__ rc, int32_t* __restrict__ ex,
                                                     int32_t* __restrict__ snk, int32_t* __restrict__ dist,
                                                     const int32_t* __restrict__ tact_in, int32_t* __restrict__ tact_out) {
     __shared__ int s_ex[256];
     __shared__ int s_d[10][34];
     __shared__ int s_rc[8][256];
-    const int b = blockIdx.z;
-    if (done[b]) return;
+    const int b = open_list[blockIdx.z];
     const int tile = (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (!tact_in[tile]) return;
     const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
@@ -688,11 +691,10 @@ __global__ void __launch_bounds__(256) k_mf_pr_tile(GcDims d, int inner, const i
     }
 }
 
-__global__ void __launch_bounds__(256) k_mf_active(GcDims d, const int32_t* __restrict__ done, const int32_t* __restrict__ ex,
+__global__ void __launch_bounds__(256) k_mf_active(GcDims d, const int32_t* __restrict__ open_list, const int32_t* __restrict__ ex,
                                                    const int32_t* __restrict__ dist, int32_t* __restrict__ active,
                                                    int32_t* __restrict__ tact, int tiles_x, int tiles_y) {
-    const int b = blockIdx.y;
-    if (done[b]) return;
+    const int b = open_list[blockIdx.y];
     int n = 0;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.P; p += gridDim.x * blockDim.x) {
         const bool a = ex[(size_t)b * d.P + p] > 0 && dist[(size_t)b * d.P + p] < DINF;
@@ -721,10 +723,17 @@ __global__ void k_copy_i32(int n, const int32_t* src, int32_t* dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
 }
-__global__ void k_done_update(int B, const int32_t* __restrict__ active, int32_t* __restrict__ done, int32_t* __restrict__ n_open) {
+// closes images without active pixels and compacts the still-open ones into the next launch list
+__global__ void k_done_update(int n_cur, const int32_t* __restrict__ list_cur, const int32_t* __restrict__ active,
+                              int32_t* __restrict__ list_nxt, int32_t* __restrict__ n_open) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cur) return;
+    const int b = list_cur[i];
+    if (active[b] != 0) list_nxt[atomicAdd(n_open, 1)] = b;
+}
+__global__ void k_open_init(int B, const int32_t* __restrict__ state, int32_t* __restrict__ list, int32_t* __restrict__ n_open) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    if (!done[b]) { if (active[b] == 0) done[b] = 1; else atomicAdd(n_open, 1); }
+    if (b < B && !state[b]) list[atomicAdd(n_open, 1)] = b;
 }
 
 // ---------------------------------------------------------------- host driver
@@ -736,73 +745,88 @@ static int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std
 }
 
 static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
-                   int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* done,
+                   int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists /*[2B] open-image lists*/,
                    int32_t* flags /*[B] changed | [B] active | [1] n_open*/) {
     const int B = d.B;
-    const size_t BP = (size_t)B * d.P;
     int32_t* changed = flags;
     int32_t* active = flags + B;
     int32_t* n_open = flags + 2 * B;
-    const dim3 tiles(cdiv(d.W, 32), cdiv(d.H, 8), B);
-    const size_t n_tiles = (size_t)tiles.x * tiles.y * B;
+    const int tiles_x = cdiv(d.W, 32), tiles_y = cdiv(d.H, 8);
+    const size_t n_tiles = (size_t)tiles_x * tiles_y * B;
     int32_t* tact_a = scratch_t<int32_t>(ctx, S_GC_M, n_tiles * 2);
     if (!tact_a) return GGC_E_OOM;
     int32_t* tact_b = tact_a + n_tiles;
-    int32_t* front_a = scratch_t<int32_t>(ctx, S_GC_N, (size_t)cdiv(d.W, RT) * cdiv(d.H, RT) * B * 2);
+    const int rt_x = cdiv(d.W, RT), rt_y = cdiv(d.H, RT);
+    const size_t n_rt = (size_t)rt_x * rt_y * B;
+    int32_t* front_a = scratch_t<int32_t>(ctx, S_GC_N, n_rt * 2);
     if (!front_a) return GGC_E_OOM;
-    hipLaunchKernelGGL(k_copy_i32, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, done);
+    int32_t *list_cur = lists, *list_nxt = lists + B;
     std::vector<int32_t> host;
+    GGC_HIP(ctx, hipMemsetAsync(n_open, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_open_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, list_cur, n_open);
+    GGC_LAUNCH_CHECK(ctx);
+    int rcode = read_i32(ctx, st, n_open, 1, host);
+    if (rcode) return rcode;
+    int n_cur = host[0];
+    if (n_cur == 0) return GGC_OK;
+    const bool trace = std::getenv("GGC_MF_TRACE") != nullptr;
     const int max_rounds = 4096;
     for (int round = 0; round < max_rounds; ++round) {
-        // ---- global relabel
+        // ---- global relabel of the open images
         {
             ProfScope prof(ctx, st, "maxflow_relabel");
-            hipLaunchKernelGGL(k_mf_dinit, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, done, snk, rc, dist, rmask);
-            const dim3 rtiles(cdiv(d.W, RT), cdiv(d.H, RT), B);
-            const size_t n_rt = (size_t)rtiles.x * rtiles.y * B;
+            hipLaunchKernelGGL(k_mf_dinit, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
+            const dim3 rtiles(rt_x, rt_y, n_cur);
             int32_t *fr_cur = front_a, *fr_nxt = front_a + n_rt;
             GGC_HIP(ctx, hipMemsetAsync(fr_cur, 1, sizeof(int32_t) * n_rt, st));     // every tile starts on the frontier
             for (int guard = 0; guard < 100000; ++guard) {
                 GGC_HIP(ctx, hipMemsetAsync(changed, 0, sizeof(int32_t) * B, st));
                 for (int rep = 0; rep < 4; ++rep) {
                     GGC_HIP(ctx, hipMemsetAsync(fr_nxt, 0, sizeof(int32_t) * n_rt, st));
-                    hipLaunchKernelGGL(k_mf_relax_tile, rtiles, dim3(256), 0, st, d, done, rmask, dist, changed, fr_cur, fr_nxt);
+                    hipLaunchKernelGGL(k_mf_relax_tile, rtiles, dim3(256), 0, st, d, list_cur, rmask, dist, changed, fr_cur, fr_nxt);
                     std::swap(fr_cur, fr_nxt);
                 }
                 GGC_LAUNCH_CHECK(ctx);
-                int rcode = read_i32(ctx, st, changed, B, host);
-                if (rcode) return rcode;
+                if ((rcode = read_i32(ctx, st, changed, B, host))) return rcode;
                 bool any = false;
                 for (int b = 0; b < B; ++b) any |= host[b] != 0;
                 if (!any) break;
             }
         }
-        // ---- who still has work?
+        // ---- who still has work?  (active pixel = excess that can still reach the sink)
         GGC_HIP(ctx, hipMemsetAsync(active, 0, sizeof(int32_t) * (B + 1), st));
         GGC_HIP(ctx, hipMemsetAsync(tact_a, 0, sizeof(int32_t) * n_tiles, st));
-        hipLaunchKernelGGL(k_mf_active, dim3(std::min(cdiv(d.P, 256 * 4), 128), B), dim3(256), 0, st, d, done, ex, dist, active,
-                           tact_a, (int)tiles.x, (int)tiles.y);
-        hipLaunchKernelGGL(k_done_update, dim3(cdiv(B, 256)), dim3(256), 0, st, B, active, done, n_open);
+        hipLaunchKernelGGL(k_mf_active, dim3(std::min(cdiv(d.P, 256 * 4), 128), n_cur), dim3(256), 0, st, d, list_cur, ex, dist,
+                           active, tact_a, tiles_x, tiles_y);
+        hipLaunchKernelGGL(k_done_update, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, n_cur, list_cur, active, list_nxt, n_open);
         GGC_LAUNCH_CHECK(ctx);
-        int rcode = read_i32(ctx, st, n_open, 1, host);
-        if (rcode) return rcode;
-        if (std::getenv("GGC_MF_TRACE")) {   // diagnostics: active pixels / open images per round
-            const int open = host[0];
+        if ((rcode = read_i32(ctx, st, n_open, 1, host))) return rcode;
+        const int n_next = host[0];
+        if (trace) {   // diagnostics: active pixels / open images per round
             std::vector<int32_t> act;
             if ((rcode = read_i32(ctx, st, active, B, act))) return rcode;
             long long tot = 0;
             for (int v : act) tot += v;
-            std::fprintf(stderr, "[ggc maxflow] round %d: open images %d, active pixels %lld\n", round, open, tot);
-            host[0] = open;
+            std::fprintf(stderr, "[ggc maxflow] round %d: open images %d, active pixels %lld\n", round, n_next, tot);
         }
-        if (host[0] == 0) return GGC_OK;
+        if (n_next == 0) return GGC_OK;
+        std::swap(list_cur, list_nxt);
+        n_cur = n_next;
         // ---- push-relabel sweeps
         {
             ProfScope prof(ctx, st, "maxflow_push");
             int32_t *cur = tact_a, *nxt = tact_b;
-            for (int l = 0; l < 16; ++l) {
+            // schedule measured on MI355X (tools/mf_sweep.sh): 24 launches x 8 sweeps per round, no shortened first round
+            static const int n_launch = [] { const char* e = std::getenv("GGC_MF_PR_LAUNCHES"); return e ? std::max(1, std::atoi(e)) : 24; }();
+            static const int n_inner = [] { const char* e = std::getenv("GGC_MF_PR_INNER"); return e ? std::max(1, std::atoi(e)) : 8; }();
+            // Optional shorter early rounds (GGC_MF_PR_FIRST << round launches); measured slower than a flat
+            // schedule because every extra round pays a full global relabel, so it is off by default.
+            static const int n_first = [] { const char* e = std::getenv("GGC_MF_PR_FIRST"); return e ? std::max(1, std::atoi(e)) : 4096; }();
+            const int launches_now = std::min(n_launch, n_first << std::min(round, 8));
+            const dim3 tiles(tiles_x, tiles_y, n_cur);
+            for (int l = 0; l < launches_now; ++l) {
                 GGC_HIP(ctx, hipMemsetAsync(nxt, 0, sizeof(int32_t) * n_tiles, st));
-                hipLaunchKernelGGL(k_mf_pr_tile, tiles, dim3(256), 0, st, d, 16, done, rc, ex, snk, dist, cur, nxt);
+                hipLaunchKernelGGL(k_mf_pr_tile, tiles, dim3(256), 0, st, d, n_inner, list_cur, rc, ex, snk, dist, cur, nxt);
                 std::swap(cur, nxt);
             }
             GGC_LAUNCH_CHECK(ctx);
@@ -830,7 +854,7 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
     GcDims d{B, H, W, H * W, cdiv((size_t)H * W, CHUNK)};
     const size_t BP = (size_t)B * d.P;
 
-    int32_t* small = scratch_t<int32_t>(ctx, S_GC_A, (size_t)B * 8 + 16);   // f1 | f2 | state | done | changed | active | n_open.. | err
+    int32_t* small = scratch_t<int32_t>(ctx, S_GC_A, (size_t)B * 10 + 16);  // f1 | f2 | state | done | changed | active | n_open.. | err | open lists [2B]
     Gmm* gmm = scratch_t<Gmm>(ctx, S_GC_B, (size_t)B * 2);
     unsigned long long* acc = scratch_t<unsigned long long>(ctx, S_GC_C, (size_t)B * 2 * NCOMP * ACC_W + B);
     uint8_t* comp = scratch_t<uint8_t>(ctx, S_GC_D, BP);
@@ -844,7 +868,7 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
     int32_t *f1 = small, *f2 = small + B, *state = small + 2 * B, *done = small + 3 * B, *mf_flags = small + 4 * B;
     int32_t* err = small + 8 * B;
     unsigned long long* bsum = acc + (size_t)B * 2 * NCOMP * ACC_W;
-    GGC_HIP(ctx, hipMemsetAsync(small, 0, sizeof(int32_t) * ((size_t)B * 8 + 16), st));
+    GGC_HIP(ctx, hipMemsetAsync(small, 0, sizeof(int32_t) * ((size_t)B * 10 + 16), st));
     GGC_HIP(ctx, hipMemsetAsync(acc, 0, sizeof(unsigned long long) * ((size_t)B * 2 * NCOMP * ACC_W + B), st));
 
     if (mode == 1) {
@@ -895,7 +919,7 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                 hipLaunchKernelGGL(k_build_graph, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk);
             }
             GGC_LAUNCH_CHECK(ctx);
-            int rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, done, mf_flags);
+            int rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 8 * B + 16, mf_flags);
             if (rcode) return rcode;
             hipLaunchKernelGGL(k_gc_relabel, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, state, dist, mask);
             GGC_LAUNCH_CHECK(ctx);

@@ -431,7 +431,7 @@ __device__ __forceinline__ void fma4(float4& acc, float w, const float4& v) {
 }
 
 template <int D, int MODE>
-__global__ void __launch_bounds__(256) k_aggregate(int N, const float* __restrict__ xw,
+__global__ void __launch_bounds__(1024) k_aggregate(int N, const float* __restrict__ xw,
                                                    const int32_t* __restrict__ row_ptr,
                                                    const int32_t* __restrict__ col,
                                                    const float* __restrict__ dis,
@@ -439,48 +439,60 @@ __global__ void __launch_bounds__(256) k_aggregate(int N, const float* __restric
                                                    const float* __restrict__ gate,
                                                    const float* __restrict__ h,
                                                    float* __restrict__ out) {
-    constexpr int LPR = AggCfg<D>::LPR, RPW = AggCfg<D>::RPW, RPB = AggCfg<D>::RPB;
+    constexpr int LPR = AggCfg<D>::LPR, RPW = AggCfg<D>::RPW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, sl = lane % LPR;
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
-    const int row = blk * RPB + wave * RPW + sub;
-    if (row >= N || sl * 4 >= D) return;
-    const int beg = row_ptr[row], end = row_ptr[row + 1];
-    const float di = (MODE == 0) ? dis[row] : 1.0f;
-    const float4* xw4 = reinterpret_cast<const float4*>(xw) + sl;
+    const int row = blk * (RPW * (int)(blockDim.x >> 6)) + wave * RPW + sub;
+    // The sub-group of LPR lanes that owns a row first loads up to LPR column indices (and their
+    // dis weights) with ONE coalesced load each, then broadcasts them by shuffle: the dependent
+    // chain per row is row_ptr -> col -> dis -> rows instead of one col/dis round trip per
+    // neighbour, and up to 8 neighbour rows are in flight per lane.  Summation order is unchanged
+    // (CSR = edge order, self loop last).
+    const bool rvalid = row < N, cvalid = sl * 4 < D;
+    const int rowc = rvalid ? row : 0, slc = cvalid ? sl : 0;
+    const int beg = rvalid ? row_ptr[rowc] : 0, end = rvalid ? row_ptr[rowc + 1] : 0;
+    const float di = (MODE == 0) ? dis[rowc] : 1.0f;
     constexpr int D4 = D / 4;
+    const float4* xw4 = reinterpret_cast<const float4*>(xw) + slc;
+    const size_t o4 = (size_t)rowc * D4 + slc;
+    float4 self = make_float4(0.f, 0.f, 0.f, 0.f), gt = self, hv = self;
+    if (MODE == 0) {                     // epilogue operands: issue their loads before the gather
+        self = xw4[(size_t)rowc * D4];
+        if (gate) { gt = reinterpret_cast<const float4*>(gate)[o4]; hv = reinterpret_cast<const float4*>(h)[o4]; }
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int p = beg;
-    for (; p + 4 <= end; p += 4) {
-        const int j0 = col[p], j1 = col[p + 1], j2 = col[p + 2], j3 = col[p + 3];
-        const float4 v0 = xw4[(size_t)j0 * D4], v1 = xw4[(size_t)j1 * D4];
-        const float4 v2 = xw4[(size_t)j2 * D4], v3 = xw4[(size_t)j3 * D4];
-        if (MODE == 0) {
-            const float w0 = dis[j0] * di, w1 = dis[j1] * di, w2 = dis[j2] * di, w3 = dis[j3] * di;
-            fma4(acc, w0, v0); fma4(acc, w1, v1); fma4(acc, w2, v2); fma4(acc, w3, v3);
-        } else {
-            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    for (int base = beg; base < end; base += LPR) {
+        const int n = min(LPR, end - base);
+        int c = 0;
+        float w = 0.0f;
+        if (sl < n) { c = col[base + sl]; if (MODE == 0) w = dis[c] * di; }
+        for (int k = 0; k < n; k += 8) {
+            float4 v[8];
+            float wk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = min(k + u, n - 1);
+                const int j = __shfl(c, kk, LPR);
+                wk[u] = __shfl(w, kk, LPR);
+                if (k + u < n) v[u] = xw4[(size_t)j * D4];     // predicated: no duplicate row fetches in the tail
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k + u < n) {
+                    if (MODE == 0) fma4(acc, wk[u], v[u]);
+                    else { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                }
+            }
         }
     }
-    for (; p < end; ++p) {
-        const int j = col[p];
-        const float4 v = xw4[(size_t)j * D4];
-        if (MODE == 0) fma4(acc, dis[j] * di, v);
-        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-    }
-    const size_t o4 = (size_t)row * D4 + sl;
     if (MODE == 0) {
-        fma4(acc, di * di, xw4[(size_t)row * D4]);
+        fma4(acc, di * di, self);
         if (bias) {
-            const float4 b = reinterpret_cast<const float4*>(bias)[sl];
+            const float4 b = reinterpret_cast<const float4*>(bias)[slc];
             acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
         }
         if (gate) {
-            const float4 gt = reinterpret_cast<const float4*>(gate)[o4];
-            const float4 hv = reinterpret_cast<const float4*>(h)[o4];
             acc.x = hv.x + gelu_f(acc.x * gt.x); acc.y = hv.y + gelu_f(acc.y * gt.y);
             acc.z = hv.z + gelu_f(acc.z * gt.z); acc.w = hv.w + gelu_f(acc.w * gt.w);
         }
@@ -489,7 +501,99 @@ __global__ void __launch_bounds__(256) k_aggregate(int N, const float* __restric
         const float c = (float)(cnt > 0 ? cnt : 1);
         acc.x /= c; acc.y /= c; acc.z /= c; acc.w /= c;
     }
-    reinterpret_cast<float4*>(out)[o4] = acc;
+    if (rvalid && cvalid) reinterpret_cast<float4*>(out)[o4] = acc;
+}
+
+// LDS-windowed form of the gather.  PMC profiling of the kernel above shows ideal HBM traffic
+// (FETCH+WRITE == algorithmic bytes) but the per-CU L1/texture path ~76 % busy: every neighbour row
+// costs a 16-cycle slot of the 64 B/clk vector-memory pipe.  About half of the edges are region
+// adjacencies whose endpoints are a few dozen node ids apart (superpixels are numbered in raster
+// order), so a block that owns S consecutive rows first copies the window [s0-HALO, s0+S+HALO) of xw
+// into LDS with fully coalesced loads and then serves every neighbour inside the window — and the
+// self loop — by ds_read_b128, which runs on the separate 256 B/clk LDS pipe.  Only the non-local
+// colour edges still go to L2.  Arithmetic and summation order are unchanged.
+template <int D> struct AggLds {
+    static constexpr int S = 96, HALO = 32, WIN = S + 2 * HALO;
+    static constexpr size_t BYTES = (size_t)WIN * D * sizeof(float);
+};
+
+template <int D, int MODE>
+__global__ void __launch_bounds__(512) k_aggregate_lds(int N, const float* __restrict__ xw,
+                                                       const int32_t* __restrict__ row_ptr,
+                                                       const int32_t* __restrict__ col,
+                                                       const float* __restrict__ dis,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ gate,
+                                                       const float* __restrict__ h,
+                                                       float* __restrict__ out) {
+    constexpr int LPR = AggCfg<D>::LPR, RPW = AggCfg<D>::RPW, D4 = D / 4;
+    constexpr int S = AggLds<D>::S, HALO = AggLds<D>::HALO;
+    extern __shared__ float4 tile[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int s0 = blk * S;
+    const int w0 = max(s0 - HALO, 0), w1 = min(s0 + S + HALO, N);
+    const int nwin = w1 - w0;
+    const float4* xw4g = reinterpret_cast<const float4*>(xw);
+    for (int i = tid; i < nwin * D4; i += 512) tile[i] = xw4g[(size_t)w0 * D4 + i];
+    __syncthreads();
+    const bool cvalid = sl * 4 < D;
+    const int slc = cvalid ? sl : 0;
+    for (int r = wave * RPW + sub; r < S; r += 8 * RPW) {
+        const int row = s0 + r;
+        const bool rvalid = row < N;
+        const int rowc = rvalid ? row : s0;
+        const int beg = rvalid ? row_ptr[rowc] : 0, end = rvalid ? row_ptr[rowc + 1] : 0;
+        const float di = (MODE == 0) ? dis[rowc] : 1.0f;
+        const size_t o4 = (size_t)rowc * D4 + slc;
+        float4 gt = make_float4(0.f, 0.f, 0.f, 0.f), hv = gt;
+        if (MODE == 0 && gate) { gt = reinterpret_cast<const float4*>(gate)[o4]; hv = reinterpret_cast<const float4*>(h)[o4]; }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = beg; base < end; base += LPR) {
+            const int n = min(LPR, end - base);
+            int c = 0;
+            float w = 0.0f;
+            if (sl < n) { c = col[base + sl]; if (MODE == 0) w = dis[c] * di; }
+            for (int k = 0; k < n; k += 8) {
+                float4 v[8];
+                float wk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = min(k + u, n - 1);
+                    const int j = __shfl(c, kk, LPR);
+                    wk[u] = __shfl(w, kk, LPR);
+                    if (k + u < n) {
+                        const int off = j - w0;
+                        v[u] = ((unsigned)off < (unsigned)nwin) ? tile[off * D4 + slc] : xw4g[(size_t)j * D4 + slc];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k + u < n) {
+                        if (MODE == 0) fma4(acc, wk[u], v[u]);
+                        else { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                    }
+                }
+            }
+        }
+        if (MODE == 0) {
+            fma4(acc, di * di, tile[(rowc - w0) * D4 + slc]);
+            if (bias) {
+                const float4 b = reinterpret_cast<const float4*>(bias)[slc];
+                acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+            }
+            if (gate) {
+                acc.x = hv.x + gelu_f(acc.x * gt.x); acc.y = hv.y + gelu_f(acc.y * gt.y);
+                acc.z = hv.z + gelu_f(acc.z * gt.z); acc.w = hv.w + gelu_f(acc.w * gt.w);
+            }
+        } else {
+            const int cnt = end - beg;
+            const float cf = (float)(cnt > 0 ? cnt : 1);
+            acc.x /= cf; acc.y /= cf; acc.z /= cf; acc.w /= cf;
+        }
+        if (rvalid && cvalid) reinterpret_cast<float4*>(out)[o4] = acc;
+    }
 }
 
 // ----------------------------------------------------------------- M5: JK fusion
@@ -719,7 +823,25 @@ static int launch_aggregate(ggc_ctx* ctx, hipStream_t st, int N, const float* xw
                             const int32_t* col, const float* dis, const float* bias, const float* gate,
                             const float* h, float* out) {
     ProfScope prof(ctx, st, MODE == 0 ? "gcn_aggregate" : "sage_aggregate");
-    hipLaunchKernelGGL((k_aggregate<D, MODE>), dim3(cdiv(N, AggCfg<D>::RPB)), dim3(256), 0, st,
+    // A/B switch: the LDS-windowed variant is bit-identical but currently slower (127 vs 94 us at batch 256:
+    // the window fill is not overlapped with the gather yet), so the direct L2 gather stays the default.
+    static const bool use_lds = [] { const char* e = std::getenv("GGC_AGG_LDS"); return e && e[0] == '1'; }();
+    if (use_lds) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate_lds<D, MODE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)AggLds<D>::BYTES));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_aggregate_lds<D, MODE>), dim3(cdiv(N, AggLds<D>::S)), dim3(512), AggLds<D>::BYTES, st,
+                           N, xw, row_ptr, col, dis, bias, gate, h, out);
+        GGC_LAUNCH_CHECK(ctx);
+        return GGC_OK;
+    }
+    static const int threads = [] { const char* e = std::getenv("GGC_AGG_THREADS"); const int t = e ? std::atoi(e) : 256;
+                                    return (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) ? t : 256; }();
+    const int rows_per_block = AggCfg<D>::RPW * (threads / 64);
+    hipLaunchKernelGGL((k_aggregate<D, MODE>), dim3(cdiv(N, rows_per_block)), dim3(threads), 0, st,
                        N, xw, row_ptr, col, dis, bias, gate, h, out);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
