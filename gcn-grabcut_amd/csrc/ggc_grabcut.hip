@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) k_km_assign(GcDims d, const uint8_t* __re
                                                    const uint8_t* __restrict__ mask, const int32_t* __restrict__ state,
                                                    const KmState* __restrict__ km, uint8_t* __restrict__ comp,
                                                    unsigned long long* __restrict__ acc) {
-    __shared__ unsigned long long s_acc[2 * NCOMP * 4];
+    __shared__ unsigned int s_acc[2 * NCOMP * 4];     // 32-bit block-local bins (256 x 255 fits easily)
     const int b = blockIdx.y, tid = threadIdx.x;
     if (state[b]) return;
     for (int i = tid; i < 2 * NCOMP * 4; i += 256) s_acc[i] = 0;
@@ -250,13 +250,13 @@ __global__ void __launch_bounds__(256) k_km_assign(GcDims d, const uint8_t* __re
             if (k == 0 || dist < bd) { best = k; bd = dist; }
         }
         comp[gp] = (uint8_t)best;
-        unsigned long long* a = s_acc + (c * NCOMP + best) * 4;
-        atomicAdd(&a[0], 1ull); atomicAdd(&a[1], (unsigned long long)px[0]);
-        atomicAdd(&a[2], (unsigned long long)px[1]); atomicAdd(&a[3], (unsigned long long)px[2]);
+        unsigned int* a = s_acc + (c * NCOMP + best) * 4;
+        atomicAdd(&a[0], 1u); atomicAdd(&a[1], (unsigned int)px[0]);
+        atomicAdd(&a[2], (unsigned int)px[1]); atomicAdd(&a[3], (unsigned int)px[2]);
     }
     __syncthreads();
     for (int i = tid; i < 2 * NCOMP * 4; i += 256)
-        if (s_acc[i]) atomicAdd(&acc[((size_t)b * 2 * NCOMP + i / 4) * ACC_W + (i % 4)], s_acc[i]);
+        if (s_acc[i]) atomicAdd(&acc[((size_t)b * 2 * NCOMP + i / 4) * ACC_W + (i % 4)], (unsigned long long)s_acc[i]);
 }
 
 __global__ void k_km_update(int B, const int32_t* __restrict__ state, KmState* __restrict__ km,
@@ -277,10 +277,13 @@ __global__ void __launch_bounds__(256) k_gmm_accum(GcDims d, const uint8_t* __re
                                                    const uint8_t* __restrict__ mask, const int32_t* __restrict__ state,
                                                    const Gmm* __restrict__ gmm, uint8_t* __restrict__ comp,
                                                    unsigned long long* __restrict__ acc) {
-    __shared__ unsigned long long s_acc[2 * NCOMP * ACC_W];
+    // Block-local bins in LDS as 32-bit counters (256 pixels x 255^2 < 2^32), products stored once per
+    // symmetric pair: 10 LDS atomics per pixel; the exact 64-bit totals are formed by the global flush.
+    constexpr int LW = 10;   // count | 3 sums | xx xy xz yy yz zz
+    __shared__ unsigned int s_acc[2 * NCOMP * LW];
     const int b = blockIdx.y, tid = threadIdx.x;
     if (state[b]) return;
-    for (int i = tid; i < 2 * NCOMP * ACC_W; i += 256) s_acc[i] = 0;
+    for (int i = tid; i < 2 * NCOMP * LW; i += 256) s_acc[i] = 0;
     __syncthreads();
     const int p = blockIdx.x * 256 + tid;
     if (p < d.P) {
@@ -290,17 +293,25 @@ __global__ void __launch_bounds__(256) k_gmm_accum(GcDims d, const uint8_t* __re
         int ci;
         if (MODE == 1) { ci = gmm_which(gmm[b * 2 + c], px); comp[gp] = (uint8_t)ci; }
         else ci = comp[gp];
-        unsigned long long* a = s_acc + (c * NCOMP + ci) * ACC_W;
-        const unsigned long long v[3] = {px[0], px[1], px[2]};
-        atomicAdd(&a[0], 1ull);
-        for (int i = 0; i < 3; ++i) {
-            atomicAdd(&a[1 + i], v[i]);
-            for (int j = 0; j < 3; ++j) atomicAdd(&a[4 + 3 * i + j], v[i] * v[j]);
-        }
+        unsigned int* a = s_acc + (c * NCOMP + ci) * LW;
+        const unsigned int v0 = px[0], v1 = px[1], v2 = px[2];
+        atomicAdd(&a[0], 1u);
+        atomicAdd(&a[1], v0); atomicAdd(&a[2], v1); atomicAdd(&a[3], v2);
+        atomicAdd(&a[4], v0 * v0); atomicAdd(&a[5], v0 * v1); atomicAdd(&a[6], v0 * v2);
+        atomicAdd(&a[7], v1 * v1); atomicAdd(&a[8], v1 * v2); atomicAdd(&a[9], v2 * v2);
     }
     __syncthreads();
-    for (int i = tid; i < 2 * NCOMP * ACC_W; i += 256)
-        if (s_acc[i]) atomicAdd(&acc[(size_t)b * 2 * NCOMP * ACC_W + i], s_acc[i]);
+    for (int i = tid; i < 2 * NCOMP * ACC_W; i += 256) {
+        const int bin = i / ACC_W, slot = i % ACC_W;
+        int ls = slot;                                   // slots 0..3 map to themselves
+        if (slot >= 4) {                                 // 4 + 3 r + c  ->  symmetric pair index
+            const int r = (slot - 4) / 3, cc = (slot - 4) % 3;
+            const int lo = r < cc ? r : cc, hi = r < cc ? cc : r;
+            ls = 4 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5));
+        }
+        const unsigned int v = s_acc[bin * LW + ls];
+        if (v) atomicAdd(&acc[(size_t)b * 2 * NCOMP * ACC_W + i], (unsigned long long)v);
+    }
 }
 
 // endLearning: one thread per (image, class)
@@ -411,7 +422,7 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
                                                      const uint8_t* __restrict__ mask, const int32_t* __restrict__ state,
                                                      const Gmm* __restrict__ gmm, const int32_t* __restrict__ nw,
                                                      int32_t* __restrict__ rc, int32_t* __restrict__ ex,
-                                                     int32_t* __restrict__ snk) {
+                                                     int32_t* __restrict__ snk, int warm) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t BP = (size_t)d.B * d.P;
     if (i >= BP) return;
@@ -432,18 +443,29 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
         if (dv < -LAMBDA) dv = -LAMBDA;
     }
     const int32_t tw = (int32_t)rint(dv * CAP_SCALE);
-    ex[i] = tw > 0 ? tw : 0;
-    snk[i] = tw < 0 ? -tw : 0;
     const int32_t* nwb = nw + (size_t)b * d.P;
     // own planes give the arcs towards left / up-left / up / up-right; the mirrored arcs read the neighbour's plane
     const int dirs[4] = {0, 4, 2, 6};
+    int32_t inflow = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int dir = dirs[k];
-        rc[(size_t)dir * BP + i] = dir_nb(d, y, x, dir) >= 0 ? nwb[(size_t)k * BP + p] : 0;
+        const int32_t c0 = dir_nb(d, y, x, dir) >= 0 ? nwb[(size_t)k * BP + p] : 0;
         const int q = dir_nb(d, y, x, dir ^ 1);
-        rc[(size_t)(dir ^ 1) * BP + i] = q >= 0 ? nwb[(size_t)k * BP + q] : 0;
+        const int32_t c1 = q >= 0 ? nwb[(size_t)k * BP + q] : 0;
+        if (warm) {   // keep the n-link flow of the previous iteration: net inflow = sum (residual - capacity)
+            inflow += (rc[(size_t)dir * BP + i] - c0) + (rc[(size_t)(dir ^ 1) * BP + i] - c1);
+        } else {
+            rc[(size_t)dir * BP + i] = c0;
+            rc[(size_t)(dir ^ 1) * BP + i] = c1;
+        }
     }
+    // Warm start (dynamic graph cuts): only the t-links change between GrabCut iterations, and adding a
+    // constant to both t-links of a pixel never changes the cut, so the old n-link flow stays a valid
+    // preflow: the pixel's new terminal balance is its t-link difference plus what its neighbours sent it.
+    const int32_t bal = tw + inflow;
+    ex[i] = bal > 0 ? bal : 0;
+    snk[i] = bal < 0 ? -bal : 0;
 }
 
 // ------------------------------------------------------------------ max-flow
@@ -916,7 +938,9 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                 ProfScope prof(ctx, st, "grabcut_gmm");
                 hipLaunchKernelGGL((k_gmm_accum<1>), dim3(cdiv(d.P, 256), B), dim3(256), 0, st, d, image, mask, state, gmm, comp, acc);
                 hipLaunchKernelGGL(k_gmm_learn, dim3(cdiv(B * 2, 64)), dim3(64), 0, st, B, state, acc, gmm);
-                hipLaunchKernelGGL(k_build_graph, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk);
+                static const bool warm_ok = [] { const char* e = std::getenv("GGC_MF_WARM"); return !(e && e[0] == '0'); }();
+                hipLaunchKernelGGL(k_build_graph, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk,
+                                   (warm_ok && it > 0) ? 1 : 0);
             }
             GGC_LAUNCH_CHECK(ctx);
             int rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 8 * B + 16, mf_flags);

@@ -54,8 +54,13 @@ __global__ void __launch_bounds__(256) k_bbox(GDims d, const int32_t* __restrict
     if (x < d.W && y < d.H) {
         const size_t p = (size_t)b * d.H * d.W + (size_t)y * d.W + x;
         const int s = seg[p];
-        int4* bb = bbox + (size_t)b * d.Nmax + s;
-        atomicMin(&bb->x, y); atomicMax(&bb->y, y + 1); atomicMin(&bb->z, x); atomicMax(&bb->w, x + 1);
+        // the extremes of a region are always attained on its outline: interior pixels skip the atomics
+        const bool edge = x == 0 || y == 0 || x == d.W - 1 || y == d.H - 1 ||
+                          seg[p - 1] != s || seg[p + 1] != s || seg[p - d.W] != s || seg[p + d.W] != s;
+        if (edge) {
+            int4* bb = bbox + (size_t)b * d.Nmax + s;
+            atomicMin(&bb->x, y); atomicMax(&bb->y, y + 1); atomicMin(&bb->z, x); atomicMax(&bb->w, x + 1);
+        }
         const int mult = (y == 0) + (y == d.H - 1) + (x == 0) + (x == d.W - 1);
         if (mult) atomicAdd(&border[(size_t)b * d.Nmax + s], mult);
         gv = grad[p];

@@ -224,11 +224,17 @@ __global__ void __launch_bounds__(256) k_slic_assign(SlicGeom g, const float* __
 }
 
 // One lane per cluster: float32 running sums over its pixels in raster order.
-__global__ void __launch_bounds__(64) k_slic_update(SlicGeom g, const float* __restrict__ image,
-                                                    const int32_t* __restrict__ labels,
-                                                    const int32_t* __restrict__ stale,
-                                                    float* __restrict__ centers, int4* __restrict__ bounds) {
-    const int k = blockIdx.x * 64 + threadIdx.x;
+// One WAVE per cluster.  The sums must be float32 running sums in raster order (that is what
+// skimage computes), so the additions stay sequential — but the memory side does not have to be:
+// the 64 lanes read 64 consecutive labels of a window row with one coalesced load, a ballot marks
+// the cluster's pixels, the matching lanes fetch their colours, and the wave then folds the set
+// bits in ascending lane (= x) order with v_readlane broadcasts.  Same additions, same order.
+__global__ void __launch_bounds__(256) k_slic_update(SlicGeom g, const float* __restrict__ image,
+                                                     const int32_t* __restrict__ labels,
+                                                     const int32_t* __restrict__ stale,
+                                                     float* __restrict__ centers, int4* __restrict__ bounds) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= g.K) return;
     const int b = blockIdx.y;
     const size_t o = (size_t)b * g.K + k;
@@ -241,15 +247,25 @@ __global__ void __launch_bounds__(64) k_slic_update(SlicGeom g, const float* __r
     int cnt = 0;
     for (int y = bd.x; y < bd.y; ++y) {
         const size_t row = (size_t)y * g.W;
-        for (int x = bd.z; x < bd.w; ++x) {
-            if (lb[row + x] == k) {
-                const float* px = im + (row + x) * 3;
-                cnt += 1;
-                sy += (float)y; sx += (float)x;
-                s0 += px[0]; s1 += px[1]; s2 += px[2];
+        const float fy = (float)y;
+        for (int xc = bd.z; xc < bd.w; xc += 64) {
+            const int x = xc + lane;
+            const bool hit = x < bd.w && lb[row + x] == k;
+            unsigned long long bal = __ballot(hit);
+            if (!bal) continue;
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            if (hit) { const float* px = im + (row + x) * 3; c0 = px[0]; c1 = px[1]; c2 = px[2]; }
+            cnt += __popcll(bal);
+            while (bal) {
+                const int l = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                sy += fy;
+                sx += (float)(xc + l);
+                s0 += __shfl(c0, l, 64); s1 += __shfl(c1, l, 64); s2 += __shfl(c2, l, 64);
             }
         }
     }
+    if (lane != 0) return;
     const float n = (float)cnt;
     const float cy = sy / n, cx = sx / n;
     centers[o * 5 + 0] = cy; centers[o * 5 + 1] = cx;
@@ -666,7 +682,7 @@ extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, co
         }
         {
             ProfScope prof(ctx, st, "slic_update");
-            hipLaunchKernelGGL(k_slic_update, dim3(cdiv(g.K, 64), B), dim3(64), 0, st, g, km_img, raw,
+            hipLaunchKernelGGL(k_slic_update, dim3(cdiv(g.K, 4), B), dim3(256), 0, st, g, km_img, raw,
                                stale + (size_t)it * B, centers, bounds);
         }
         GGC_LAUNCH_CHECK(ctx);
