@@ -498,10 +498,11 @@ constexpr int RT_NJ = RT * RT / 256;         // pixels per thread
 __global__ void __launch_bounds__(256) k_mf_relax_tile(GcDims d, const int32_t* __restrict__ open_list,
                                                        const uint8_t* __restrict__ rmask, int32_t* __restrict__ dist,
                                                        int32_t* __restrict__ changed,
-                                                       const int32_t* __restrict__ front_in, int32_t* __restrict__ front_out) {
+                                                       int32_t* __restrict__ front_in, int32_t* __restrict__ front_out) {
     __shared__ int sd[RT + 2][RT + 2];
     const int b = open_list[blockIdx.z];
-    // frontier gating: a tile only needs another pass if it or one of its 8 neighbours changed last time
+    // frontier gating: a tile only needs another pass if it or one of its 8 neighbours changed last time.
+    // The flag buffers ping-pong; each block clears the flag it consumed, so no memset between launches.
     const int tile = (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (!front_in[tile]) return;
     const int tid = threadIdx.x;
@@ -521,6 +522,7 @@ __global__ void __launch_bounds__(256) k_mf_relax_tile(GcDims d, const int32_t* 
         msk[j] = (gx < d.W && gy < d.H) ? rmask[base + (size_t)gy * d.W + gx] : 0;
     }
     __syncthreads();
+    if (tid == 0) front_in[tile] = 0;
 #pragma unroll
     for (int j = 0; j < RT_NJ; ++j) old[j] = sd[(tid / RT) + RT_ROWS * j + 1][lx + 1];
     for (int it = 0; it < 4 * RT; ++it) {
@@ -626,7 +628,7 @@ __global__ void __launch_bounds__(256) k_mf_pr(GcDims d, int inner, const int32_
 __global__ void __launch_bounds__(256) k_mf_pr_tile(GcDims d, int inner, const int32_t* __restrict__ open_list,
                                                     int32_t* __restrict__ rc, int32_t* __restrict__ ex,
                                                     int32_t* __restrict__ snk, int32_t* __restrict__ dist,
-                                                    const int32_t* __restrict__ tact_in, int32_t* __restrict__ tact_out) {
+                                                    int32_t* __restrict__ tact_in, int32_t* __restrict__ tact_out) {
     __shared__ int s_ex[256];
     __shared__ int s_d[10][34];
     __shared__ int s_rc[8][256];
@@ -648,6 +650,7 @@ __global__ void __launch_bounds__(256) k_mf_pr_tile(GcDims d, int inner, const i
         s_d[i / 34][i % 34] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
     }
     __syncthreads();
+    if (tid == 0) tact_in[tile] = 0;          // consumed: the ping-pong buffer is clean again for the launch after next
     const int d0 = s_d[ly + 1][lx + 1];
     int sk = sk0;
     // direction -> offset as arithmetic (a runtime-indexed table would live in scratch memory)
@@ -801,10 +804,10 @@ static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t*
             const dim3 rtiles(rt_x, rt_y, n_cur);
             int32_t *fr_cur = front_a, *fr_nxt = front_a + n_rt;
             GGC_HIP(ctx, hipMemsetAsync(fr_cur, 1, sizeof(int32_t) * n_rt, st));     // every tile starts on the frontier
+            GGC_HIP(ctx, hipMemsetAsync(fr_nxt, 0, sizeof(int32_t) * n_rt, st));
             for (int guard = 0; guard < 100000; ++guard) {
                 GGC_HIP(ctx, hipMemsetAsync(changed, 0, sizeof(int32_t) * B, st));
                 for (int rep = 0; rep < 4; ++rep) {
-                    GGC_HIP(ctx, hipMemsetAsync(fr_nxt, 0, sizeof(int32_t) * n_rt, st));
                     hipLaunchKernelGGL(k_mf_relax_tile, rtiles, dim3(256), 0, st, d, list_cur, rmask, dist, changed, fr_cur, fr_nxt);
                     std::swap(fr_cur, fr_nxt);
                 }
@@ -817,7 +820,7 @@ static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t*
         }
         // ---- who still has work?  (active pixel = excess that can still reach the sink)
         GGC_HIP(ctx, hipMemsetAsync(active, 0, sizeof(int32_t) * (B + 1), st));
-        GGC_HIP(ctx, hipMemsetAsync(tact_a, 0, sizeof(int32_t) * n_tiles, st));
+        GGC_HIP(ctx, hipMemsetAsync(tact_a, 0, sizeof(int32_t) * n_tiles * 2, st));   // both ping-pong buffers
         hipLaunchKernelGGL(k_mf_active, dim3(std::min(cdiv(d.P, 256 * 4), 128), n_cur), dim3(256), 0, st, d, list_cur, ex, dist,
                            active, tact_a, tiles_x, tiles_y);
         hipLaunchKernelGGL(k_done_update, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, n_cur, list_cur, active, list_nxt, n_open);
@@ -847,7 +850,6 @@ static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t*
             const int launches_now = std::min(n_launch, n_first << std::min(round, 8));
             const dim3 tiles(tiles_x, tiles_y, n_cur);
             for (int l = 0; l < launches_now; ++l) {
-                GGC_HIP(ctx, hipMemsetAsync(nxt, 0, sizeof(int32_t) * n_tiles, st));
                 hipLaunchKernelGGL(k_mf_pr_tile, tiles, dim3(256), 0, st, d, n_inner, list_cur, rc, ex, snk, dist, cur, nxt);
                 std::swap(cur, nxt);
             }

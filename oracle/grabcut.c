@@ -202,6 +202,7 @@ typedef struct {
     int32_t *aq, aq_head, aq_tail, aq_cap;   /* active FIFO (circular) */
     uint8_t* in_aq;
     int32_t *oq, oq_n, oq_cap;               /* orphan stack processed FIFO */
+    int32_t *ts, *dist, time;                /* adoption-phase timestamps and terminal distances */
 } bk_t;
 
 static int nb(const bk_t* g, int p, int d) {
@@ -214,14 +215,22 @@ static void aq_push(bk_t* g, int p) {
     g->in_aq[p] = 1;
     g->aq[g->aq_tail] = p; g->aq_tail = (g->aq_tail + 1) % g->aq_cap;
 }
-/* does p's tree path reach a terminal (no orphan on the way)? */
-static int rooted(const bk_t* g, int p) {
+/* Distance of q to its terminal along parent links, or -1 if the path hits an orphan.  Nodes verified
+ * during the current adoption phase carry ts == time and their distance (the Boykov-Kolmogorov
+ * timestamp heuristic), so repeated walks stop early. */
+static int origin_dist(bk_t* g, int q) {
+    int d = 0, p = q;
     for (;;) {
-        const int d = g->par[p];
-        if (d == PAR_TERMINAL) return 1;
-        if (d < 0) return 0;
-        p = nb(g, p, d);
+        if (g->ts[p] == g->time) { d += g->dist[p]; break; }
+        const int dir = g->par[p];
+        if (dir == PAR_TERMINAL) { g->ts[p] = g->time; g->dist[p] = 1; d += 1; break; }
+        if (dir < 0) return -1;
+        ++d;
+        p = nb(g, p, dir);
     }
+    int dd = d;
+    for (p = q; g->ts[p] != g->time; p = nb(g, p, g->par[p])) { g->ts[p] = g->time; g->dist[p] = dd--; }
+    return d;
 }
 static void oq_push(bk_t* g, int p) {
     if (g->oq_n == g->oq_cap) { g->oq_cap *= 2; g->oq = (int32_t*)realloc(g->oq, (size_t)g->oq_cap * sizeof(int32_t)); }
@@ -307,17 +316,21 @@ static int64_t bk_maxflow(bk_t* g) {
         }
         flow += bott;
         /* ---- adoption */
+        g->time += 1;
         for (int oi = 0; oi < g->oq_n; ++oi) {
             const int p = g->oq[oi];
             if (g->par[p] != PAR_ORPHAN) continue;
             const int tr = g->tree[p];
-            int newpar = PAR_NONE;
+            int newpar = PAR_NONE, best = 0x7fffffff;
             for (int d = 0; d < 8; ++d) {
                 const int q = nb(g, p, d);
                 if (q < 0 || g->tree[q] != tr) continue;
                 const int32_t cap = (tr == T_SRC) ? g->rc[(size_t)(d ^ 1) * P + q] : g->rc[(size_t)d * P + p];
-                if (cap > 0 && rooted(g, q)) { newpar = d; break; }
+                if (cap <= 0) continue;
+                const int dq = origin_dist(g, q);
+                if (dq >= 0 && dq < best) { best = dq; newpar = d; }   /* closest valid parent */
             }
+            if (newpar >= 0) { g->ts[p] = g->time; g->dist[p] = best + 1; }
             if (newpar >= 0) { g->par[p] = (int8_t)newpar; continue; }
             for (int d = 0; d < 8; ++d) {
                 const int q = nb(g, p, d);
@@ -344,6 +357,7 @@ int64_t ggo_grid_maxflow(int H, int W, const int32_t* tw, const int32_t* nw, uin
     g.aq_cap = P + 1; g.aq = (int32_t*)malloc((size_t)g.aq_cap * sizeof(int32_t)); g.aq_head = g.aq_tail = 0;
     g.in_aq = (uint8_t*)calloc((size_t)P, 1);
     g.oq_cap = 1024; g.oq = (int32_t*)malloc((size_t)g.oq_cap * sizeof(int32_t)); g.oq_n = 0;
+    g.ts = (int32_t*)calloc((size_t)P, sizeof(int32_t)); g.dist = (int32_t*)calloc((size_t)P, sizeof(int32_t)); g.time = 0;
     memcpy(g.tw, tw, (size_t)P * sizeof(int32_t));
     /* nw planes: 0 left, 1 up-left, 2 up, 3 up-right; each undirected link feeds both arcs */
     static const int plane_dir[4] = {0, 4, 2, 6};
@@ -372,7 +386,7 @@ int64_t ggo_grid_maxflow(int H, int W, const int32_t* tw, const int32_t* nw, uin
         }
         free(q);
     }
-    free(g.rc); free(g.tw); free(g.tree); free(g.par); free(g.aq); free(g.in_aq); free(g.oq);
+    free(g.rc); free(g.tw); free(g.tree); free(g.par); free(g.aq); free(g.in_aq); free(g.oq); free(g.ts); free(g.dist);
     return flow;
 }
 
