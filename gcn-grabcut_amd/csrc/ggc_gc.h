@@ -1,0 +1,31 @@
+// ggc_gc.h — shared between ggc_grabcut.hip (GMMs, graph construction) and
+// ggc_maxflow.hip (integer push-relabel on the implicit 8-neighbour grid).
+#pragma once
+#include "ggc_internal.h"
+
+namespace ggc {
+
+constexpr int DINF = 1 << 29;      // "cannot reach the sink"
+
+struct GcDims { int B, H, W, P, n_chunks; };
+
+// directions: 0 left, 1 right, 2 up, 3 down, 4 up-left, 5 down-right, 6 up-right, 7 down-left; rev(dir) = dir ^ 1
+__device__ __forceinline__ int dir_dx(int dir) { return (dir == 0 || dir == 4 || dir == 7) ? -1 : ((dir == 1 || dir == 5 || dir == 6) ? 1 : 0); }
+__device__ __forceinline__ int dir_dy(int dir) { return (dir == 2 || dir == 4 || dir == 6) ? -1 : ((dir == 3 || dir == 5 || dir == 7) ? 1 : 0); }
+__device__ __forceinline__ int dir_nb(const GcDims& d, int y, int x, int dir) {
+    const int yy = y + dir_dy(dir), xx = x + dir_dx(dir);
+    if (xx < 0 || xx >= d.W || yy < 0 || yy >= d.H) return -1;
+    return yy * d.W + xx;
+}
+
+// Maximum preflow + canonical labels for every image with state[b] == 0.
+//   rc   [8][B][P] residual capacities (in/out)     ex, snk [B][P] excess / residual sink capacity (in/out)
+//   dist [B][P] out: distance to the sink in the final residual graph, >= DINF when unreachable (=> foreground)
+//   rmask [B][P] scratch, lists [2B] scratch, flags [2B+1] scratch
+int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
+            int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists, int32_t* flags);
+
+// small synchronous device -> host read (stream sync)
+int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std::vector<int32_t>& host);
+
+} // namespace ggc

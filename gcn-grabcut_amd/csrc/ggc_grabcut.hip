@@ -12,13 +12,9 @@
 // atomics) or a fixed IEEE sequence (det_exp / det_log), so the mask equals the
 // CPU path bit for bit.
 //
-// Max-flow: lock-free push-relabel (Hong 2008) on the implicit 8-neighbour grid
-// with int32 capacities, one thread per pixel, all images of the batch in one
-// launch; exact distance labels come from a periodic global relabel (backward
-// BFS from the sink as an in-place min-plus relaxation).  Only phase 1 (maximum
-// preflow) is needed: a pixel is foreground iff it cannot reach the sink in the
-// residual graph, which is what the final relabel computes.
-#include "ggc_internal.h"
+// The max-flow itself (lock-free push-relabel on LDS-resident tiles driven by work
+// lists, warm-started across the GrabCut iterations) lives in ggc_maxflow.hip.
+#include "ggc_gc.h"
 #include "ggc_math.h"
 #include <algorithm>
 #include <cmath>
@@ -29,10 +25,8 @@ namespace ggc {
 constexpr int NCOMP = 5;
 constexpr double CAP_SCALE = 262144.0;   // 2^18
 constexpr double GAMMA = 50.0, LAMBDA = 9.0 * GAMMA;
-constexpr int DINF = 1 << 29;
 constexpr int CHUNK = 1024;              // pixels per k-means++ sampling chunk
 
-struct GcDims { int B, H, W, P, n_chunks; };
 
 struct Gmm {
     double coef[NCOMP], mean[NCOMP][3], cov[NCOMP][9];
@@ -408,15 +402,6 @@ __global__ void __launch_bounds__(256) k_nweights(GcDims d, const uint8_t* __res
     }
 }
 
-// directions: 0 left, 1 right, 2 up, 3 down, 4 up-left, 5 down-right, 6 up-right, 7 down-left; rev(dir) = dir ^ 1
-__device__ __forceinline__ int dir_nb(const GcDims& d, int y, int x, int dir) {
-    const int dx = (dir == 0 || dir == 4 || dir == 7) ? -1 : ((dir == 1 || dir == 5 || dir == 6) ? 1 : 0);
-    const int dy = (dir == 2 || dir == 4 || dir == 6) ? -1 : ((dir == 3 || dir == 5 || dir == 7) ? 1 : 0);
-    const int yy = y + dy, xx = x + dx;
-    if (xx < 0 || xx >= d.W || yy < 0 || yy >= d.H) return -1;
-    return yy * d.W + xx;
-}
-
 // constructGCGraph: t-links cancelled against each other, clamped to +-lambda; residual arcs from the n-link planes
 __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __restrict__ img,
                                                      const uint8_t* __restrict__ mask, const int32_t* __restrict__ state,
@@ -468,268 +453,6 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
     snk[i] = bal < 0 ? -bal : 0;
 }
 
-// ------------------------------------------------------------------ max-flow
-__device__ __forceinline__ int ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// start of a global relabel: d = 1 next to the sink, infinity elsewhere; rmask bit dir = residual arc p -> nb(dir)
-// All max-flow kernels run over the compacted list of images that still have active pixels
-// (open_list, grid z or y = number of open images): late rounds typically have 1-5 open images out of 256.
-__global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __restrict__ open_list, const int32_t* __restrict__ snk,
-                                                  const int32_t* __restrict__ rc, int32_t* __restrict__ dist,
-                                                  uint8_t* __restrict__ rmask) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t BP = (size_t)d.B * d.P;
-    if (p >= d.P) return;
-    const size_t i = (size_t)open_list[blockIdx.y] * d.P + p;
-    dist[i] = snk[i] > 0 ? 1 : DINF;
-    int m = 0;
-#pragma unroll
-    for (int dir = 0; dir < 8; ++dir) m |= (rc[(size_t)dir * BP + i] > 0) ? (1 << dir) : 0;
-    rmask[i] = (uint8_t)m;
-}
-
-// Global relabel, tile-resident: a 32x32 pixel tile plus a one-pixel halo of distance labels lives in
-// LDS; the block relaxes d(u) = min(d(u), d(v) + 1 over residual arcs u -> v) in place until the tile
-// is stable (halo fixed), then writes back.  Launches repeat until no tile changes, so the number of
-// launches is the BFS depth measured in tiles rather than in pixels.
-constexpr int RT = 32;                       // tile side (64 measured 2x slower: longer local fixpoints)
-constexpr int RT_ROWS = 256 / RT;            // tile rows covered by one pass of the 256 threads
-constexpr int RT_NJ = RT * RT / 256;         // pixels per thread
-__global__ void __launch_bounds__(256) k_mf_relax_tile(GcDims d, const int32_t* __restrict__ open_list,
-                                                       const uint8_t* __restrict__ rmask, int32_t* __restrict__ dist,
-                                                       int32_t* __restrict__ changed,
-                                                       int32_t* __restrict__ front_in, int32_t* __restrict__ front_out) {
-    __shared__ int sd[RT + 2][RT + 2];
-    const int b = open_list[blockIdx.z];
-    // frontier gating: a tile only needs another pass if it or one of its 8 neighbours changed last time.
-    // The flag buffers ping-pong; each block clears the flag it consumed, so no memset between launches.
-    const int tile = (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (!front_in[tile]) return;
-    const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * RT, ty0 = blockIdx.y * RT;
-    const size_t base = (size_t)b * d.P;
-    for (int i = tid; i < (RT + 2) * (RT + 2); i += 256) {
-        const int ly = i / (RT + 2), lx = i % (RT + 2);
-        const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
-        sd[ly][lx] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
-    }
-    const int lx = tid % RT;
-    int msk[RT_NJ], old[RT_NJ];
-#pragma unroll
-    for (int j = 0; j < RT_NJ; ++j) {
-        const int ly = (tid / RT) + RT_ROWS * j;
-        const int gy = ty0 + ly, gx = tx0 + lx;
-        msk[j] = (gx < d.W && gy < d.H) ? rmask[base + (size_t)gy * d.W + gx] : 0;
-    }
-    __syncthreads();
-    if (tid == 0) front_in[tile] = 0;
-#pragma unroll
-    for (int j = 0; j < RT_NJ; ++j) old[j] = sd[(tid / RT) + RT_ROWS * j + 1][lx + 1];
-    for (int it = 0; it < 4 * RT; ++it) {
-        int ch = 0;
-#pragma unroll
-        for (int j = 0; j < RT_NJ; ++j) {
-            if (!msk[j]) continue;
-            const int ly = (tid / RT) + RT_ROWS * j + 1, cx = lx + 1;
-            int nd = DINF;
-            if (msk[j] & 1) nd = min(nd, sd[ly][cx - 1]);
-            if (msk[j] & 2) nd = min(nd, sd[ly][cx + 1]);
-            if (msk[j] & 4) nd = min(nd, sd[ly - 1][cx]);
-            if (msk[j] & 8) nd = min(nd, sd[ly + 1][cx]);
-            if (msk[j] & 16) nd = min(nd, sd[ly - 1][cx - 1]);
-            if (msk[j] & 32) nd = min(nd, sd[ly + 1][cx + 1]);
-            if (msk[j] & 64) nd = min(nd, sd[ly - 1][cx + 1]);
-            if (msk[j] & 128) nd = min(nd, sd[ly + 1][cx - 1]);
-            if (nd < DINF && nd + 1 < sd[ly][cx]) { sd[ly][cx] = nd + 1; ch = 1; }
-        }
-        if (!__syncthreads_or(ch)) break;
-    }
-    int any = 0;
-#pragma unroll
-    for (int j = 0; j < RT_NJ; ++j) {
-        const int ly = (tid / RT) + RT_ROWS * j;
-        const int v = sd[ly + 1][lx + 1];
-        if (v != old[j]) { dist[base + (size_t)(ty0 + ly) * d.W + tx0 + lx] = v; any = 1; }
-    }
-    if (__syncthreads_or(any) && tid < 9) {
-        if (tid == 0) atomicOr(&changed[b], 1);
-        const int ty = (int)blockIdx.y + tid / 3 - 1, tx = (int)blockIdx.x + tid % 3 - 1;
-        if (ty >= 0 && ty < (int)gridDim.y && tx >= 0 && tx < (int)gridDim.x)
-            front_out[(b * gridDim.y + ty) * gridDim.x + tx] = 1;
-    }
-}
-
-// lock-free push-relabel sweep(s): every active pixel pushes to its lowest residual neighbour or relabels
-// Activity is sparse after the first round (about 1 % of the pixels), so the grid is gated by a per-tile
-// flag: tact_in says whether the 32x8 tile held (or was handed) excess; tact_out collects the tiles that
-// must run in the next launch (own leftover excess, or a push into a neighbouring tile).
-__global__ void __launch_bounds__(256) k_mf_pr(GcDims d, int inner, const int32_t* __restrict__ done,
-                                               int32_t* __restrict__ rc, int32_t* __restrict__ ex,
-                                               int32_t* __restrict__ snk, int32_t* __restrict__ dist,
-                                               const int32_t* __restrict__ tact_in, int32_t* __restrict__ tact_out) {
-    const int b = blockIdx.z;
-    if (done[b]) return;
-    const int tile = (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (!tact_in[tile]) return;
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    const bool inb = x < d.W && y < d.H;
-    const size_t BP = (size_t)d.B * d.P, base = (size_t)b * d.P;
-    const int p = y * d.W + x;
-    int nbi[8];
-    if (inb)
-#pragma unroll
-        for (int dir = 0; dir < 8; ++dir) nbi[dir] = dir_nb(d, y, x, dir);
-    for (int it = 0; it < inner; ++it) {
-        if (inb) {
-            const int e = ld(&ex[base + p]);
-            const int dp = ld(&dist[base + p]);
-            if (e > 0 && dp < d.P) {
-                int hmin = DINF, best = -1;
-                const int sk = snk[base + p];
-                if (sk > 0) { hmin = 0; best = 8; }
-#pragma unroll
-                for (int dir = 0; dir < 8; ++dir)
-                    if (nbi[dir] >= 0 && ld(&rc[(size_t)dir * BP + base + p]) > 0) {
-                        const int hq = ld(&dist[base + nbi[dir]]);
-                        if (hq < hmin) { hmin = hq; best = dir; }
-                    }
-                if (best >= 0 && dp > hmin) {
-                    if (best == 8) {
-                        const int dl = min(e, sk);
-                        snk[base + p] = sk - dl;
-                        atomicSub(&ex[base + p], dl);
-                    } else {
-                        const int dl = min(e, ld(&rc[(size_t)best * BP + base + p]));
-                        atomicSub(&rc[(size_t)best * BP + base + p], dl);
-                        atomicAdd(&rc[(size_t)(best ^ 1) * BP + base + nbi[best]], dl);
-                        atomicSub(&ex[base + p], dl);
-                        atomicAdd(&ex[base + nbi[best]], dl);
-                        const int qy = nbi[best] / d.W, qx = nbi[best] - qy * d.W;
-                        tact_out[(b * gridDim.y + (qy >> 3)) * gridDim.x + (qx >> 5)] = 1;
-                    }
-                } else {
-                    const int nd = (best >= 0 && hmin < DINF) ? hmin + 1 : DINF;
-                    __hip_atomic_store(&dist[base + p], nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (inb && ld(&ex[base + p]) > 0 && ld(&dist[base + p]) < d.P) tact_out[tile] = 1;
-}
-
-// Tile-resident form of the sweep above: a 32x8 tile's excess, residual capacities and labels (plus a
-// one-pixel halo of labels) live in LDS for `inner` iterations, so an iteration costs LDS traffic only.
-// Pushes that stay inside the tile use LDS atomics; pushes across the tile edge go straight to global
-// memory with atomics.  Because a neighbouring tile may add to this tile's global excess / reverse
-// capacities while it runs, the write-back applies DELTAS atomically instead of storing values.  Every
-// value read stale is a lower bound of the true one (others only add excess / capacity and labels only
-// grow), which is exactly the asynchrony the lock-free algorithm tolerates.
-__global__ void __launch_bounds__(256) k_mf_pr_tile(GcDims d, int inner, const int32_t* __restrict__ open_list,
-                                                    int32_t* __restrict__ rc, int32_t* __restrict__ ex,
-                                                    int32_t* __restrict__ snk, int32_t* __restrict__ dist,
-                                                    int32_t* __restrict__ tact_in, int32_t* __restrict__ tact_out) {
-    __shared__ int s_ex[256];
-    __shared__ int s_d[10][34];
-    __shared__ int s_rc[8][256];
-    const int b = open_list[blockIdx.z];
-    const int tile = (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (!tact_in[tile]) return;
-    const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
-    const int x = blockIdx.x * 32 + lx, y = blockIdx.y * 8 + ly;
-    const bool inb = x < d.W && y < d.H;
-    const size_t BP = (size_t)d.B * d.P, base = (size_t)b * d.P;
-    const int p = y * d.W + x;
-    int e0 = 0, sk0 = 0, r0[8];
-    if (inb) { e0 = ex[base + p]; sk0 = snk[base + p]; }
-    s_ex[tid] = e0;
-#pragma unroll
-    for (int dir = 0; dir < 8; ++dir) { r0[dir] = inb ? rc[(size_t)dir * BP + base + p] : 0; s_rc[dir][tid] = r0[dir]; }
-    for (int i = tid; i < 10 * 34; i += 256) {
-        const int gy = blockIdx.y * 8 + i / 34 - 1, gx = blockIdx.x * 32 + i % 34 - 1;
-        s_d[i / 34][i % 34] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
-    }
-    __syncthreads();
-    if (tid == 0) tact_in[tile] = 0;          // consumed: the ping-pong buffer is clean again for the launch after next
-    const int d0 = s_d[ly + 1][lx + 1];
-    int sk = sk0;
-    // direction -> offset as arithmetic (a runtime-indexed table would live in scratch memory)
-    auto ddx = [](int dir) { return (dir == 0 || dir == 4 || dir == 7) ? -1 : ((dir == 1 || dir == 5 || dir == 6) ? 1 : 0); };
-    auto ddy = [](int dir) { return (dir == 2 || dir == 4 || dir == 6) ? -1 : ((dir == 3 || dir == 5 || dir == 7) ? 1 : 0); };
-    for (int it = 0; it < inner; ++it) {
-        int act = 0;
-        if (inb) {
-            const int e = __hip_atomic_load(&s_ex[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int dp = s_d[ly + 1][lx + 1];
-            if (e > 0 && dp < d.P) {
-                act = 1;
-                int hmin = DINF, best = -1;
-                if (sk > 0) { hmin = 0; best = 8; }
-#pragma unroll
-                for (int dir = 0; dir < 8; ++dir)
-                    if (__hip_atomic_load(&s_rc[dir][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) {
-                        const int hq = s_d[ly + 1 + ddy(dir)][lx + 1 + ddx(dir)];
-                        if (hq < hmin) { hmin = hq; best = dir; }
-                    }
-                if (best >= 0 && dp > hmin) {
-                    if (best == 8) {
-                        const int dl = min(e, sk);
-                        sk -= dl;
-                        atomicSub(&s_ex[tid], dl);
-                    } else {
-                        const int dl = min(e, __hip_atomic_load(&s_rc[best][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        atomicSub(&s_rc[best][tid], dl);
-                        atomicSub(&s_ex[tid], dl);
-                        const int bx = ddx(best), by = ddy(best);
-                        const int qlx = lx + bx, qly = ly + by;
-                        if (qlx >= 0 && qlx < 32 && qly >= 0 && qly < 8) {
-                            const int qt = qly * 32 + qlx;
-                            atomicAdd(&s_rc[best ^ 1][qt], dl);
-                            atomicAdd(&s_ex[qt], dl);
-                        } else {
-                            const int q = p + by * d.W + bx;
-                            atomicAdd(&rc[(size_t)(best ^ 1) * BP + base + q], dl);
-                            atomicAdd(&ex[base + q], dl);
-                            const int qy = y + by, qx = x + bx;
-                            tact_out[(b * gridDim.y + (qy >> 3)) * gridDim.x + (qx >> 5)] = 1;
-                        }
-                    }
-                } else {
-                    s_d[ly + 1][lx + 1] = (best >= 0 && hmin < DINF) ? hmin + 1 : DINF;
-                }
-            }
-        }
-        if (!__syncthreads_or(act)) break;
-    }
-    if (inb) {
-        const int e1 = s_ex[tid];
-        if (e1 != e0) atomicAdd(&ex[base + p], e1 - e0);
-#pragma unroll
-        for (int dir = 0; dir < 8; ++dir) {
-            const int r1 = s_rc[dir][tid];
-            if (r1 != r0[dir]) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[dir]);
-        }
-        if (sk != sk0) snk[base + p] = sk;
-        const int d1 = s_d[ly + 1][lx + 1];
-        if (d1 != d0) dist[base + p] = d1;
-        if (e1 > 0 && d1 < d.P) tact_out[tile] = 1;
-    }
-}
-
-__global__ void __launch_bounds__(256) k_mf_active(GcDims d, const int32_t* __restrict__ open_list, const int32_t* __restrict__ ex,
-                                                   const int32_t* __restrict__ dist, int32_t* __restrict__ active,
-                                                   int32_t* __restrict__ tact, int tiles_x, int tiles_y) {
-    const int b = open_list[blockIdx.y];
-    int n = 0;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.P; p += gridDim.x * blockDim.x) {
-        const bool a = ex[(size_t)b * d.P + p] > 0 && dist[(size_t)b * d.P + p] < DINF;
-        if (a) { const int y = p / d.W, x = p - y * d.W; tact[(b * tiles_y + (y >> 3)) * tiles_x + (x >> 5)] = 1; }
-        n += a ? 1 : 0;
-    }
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&active[b], n);
-}
-
 // estimateSegmentation: probable pixels take the side of the cut; foreground = cannot reach the sink
 __global__ void __launch_bounds__(256) k_gc_relabel(GcDims d, const int32_t* __restrict__ state,
                                                     const int32_t* __restrict__ dist, uint8_t* __restrict__ mask) {
@@ -742,121 +465,6 @@ __global__ void __launch_bounds__(256) k_gc_relabel(GcDims d, const int32_t* __r
 __global__ void __launch_bounds__(256) k_gc_binary(size_t n, const uint8_t* __restrict__ mask, uint8_t* __restrict__ binary) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) binary[i] = (mask[i] == GGC_FGD || mask[i] == GGC_PR_FGD) ? 1 : 0;
-}
-
-__global__ void k_copy_i32(int n, const int32_t* src, int32_t* dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[i];
-}
-// closes images without active pixels and compacts the still-open ones into the next launch list
-__global__ void k_done_update(int n_cur, const int32_t* __restrict__ list_cur, const int32_t* __restrict__ active,
-                              int32_t* __restrict__ list_nxt, int32_t* __restrict__ n_open) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_cur) return;
-    const int b = list_cur[i];
-    if (active[b] != 0) list_nxt[atomicAdd(n_open, 1)] = b;
-}
-__global__ void k_open_init(int B, const int32_t* __restrict__ state, int32_t* __restrict__ list, int32_t* __restrict__ n_open) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && !state[b]) list[atomicAdd(n_open, 1)] = b;
-}
-
-// ---------------------------------------------------------------- host driver
-static int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std::vector<int32_t>& host) {
-    host.resize(n);
-    GGC_HIP(ctx, hipMemcpyAsync(host.data(), dev, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
-    GGC_HIP(ctx, hipStreamSynchronize(st));
-    return GGC_OK;
-}
-
-static int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
-                   int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists /*[2B] open-image lists*/,
-                   int32_t* flags /*[B] changed | [B] active | [1] n_open*/) {
-    const int B = d.B;
-    int32_t* changed = flags;
-    int32_t* active = flags + B;
-    int32_t* n_open = flags + 2 * B;
-    const int tiles_x = cdiv(d.W, 32), tiles_y = cdiv(d.H, 8);
-    const size_t n_tiles = (size_t)tiles_x * tiles_y * B;
-    int32_t* tact_a = scratch_t<int32_t>(ctx, S_GC_M, n_tiles * 2);
-    if (!tact_a) return GGC_E_OOM;
-    int32_t* tact_b = tact_a + n_tiles;
-    const int rt_x = cdiv(d.W, RT), rt_y = cdiv(d.H, RT);
-    const size_t n_rt = (size_t)rt_x * rt_y * B;
-    int32_t* front_a = scratch_t<int32_t>(ctx, S_GC_N, n_rt * 2);
-    if (!front_a) return GGC_E_OOM;
-    int32_t *list_cur = lists, *list_nxt = lists + B;
-    std::vector<int32_t> host;
-    GGC_HIP(ctx, hipMemsetAsync(n_open, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_open_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, list_cur, n_open);
-    GGC_LAUNCH_CHECK(ctx);
-    int rcode = read_i32(ctx, st, n_open, 1, host);
-    if (rcode) return rcode;
-    int n_cur = host[0];
-    if (n_cur == 0) return GGC_OK;
-    const bool trace = std::getenv("GGC_MF_TRACE") != nullptr;
-    const int max_rounds = 4096;
-    for (int round = 0; round < max_rounds; ++round) {
-        // ---- global relabel of the open images
-        {
-            ProfScope prof(ctx, st, "maxflow_relabel");
-            hipLaunchKernelGGL(k_mf_dinit, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
-            const dim3 rtiles(rt_x, rt_y, n_cur);
-            int32_t *fr_cur = front_a, *fr_nxt = front_a + n_rt;
-            GGC_HIP(ctx, hipMemsetAsync(fr_cur, 1, sizeof(int32_t) * n_rt, st));     // every tile starts on the frontier
-            GGC_HIP(ctx, hipMemsetAsync(fr_nxt, 0, sizeof(int32_t) * n_rt, st));
-            for (int guard = 0; guard < 100000; ++guard) {
-                GGC_HIP(ctx, hipMemsetAsync(changed, 0, sizeof(int32_t) * B, st));
-                for (int rep = 0; rep < 4; ++rep) {
-                    hipLaunchKernelGGL(k_mf_relax_tile, rtiles, dim3(256), 0, st, d, list_cur, rmask, dist, changed, fr_cur, fr_nxt);
-                    std::swap(fr_cur, fr_nxt);
-                }
-                GGC_LAUNCH_CHECK(ctx);
-                if ((rcode = read_i32(ctx, st, changed, B, host))) return rcode;
-                bool any = false;
-                for (int b = 0; b < B; ++b) any |= host[b] != 0;
-                if (!any) break;
-            }
-        }
-        // ---- who still has work?  (active pixel = excess that can still reach the sink)
-        GGC_HIP(ctx, hipMemsetAsync(active, 0, sizeof(int32_t) * (B + 1), st));
-        GGC_HIP(ctx, hipMemsetAsync(tact_a, 0, sizeof(int32_t) * n_tiles * 2, st));   // both ping-pong buffers
-        hipLaunchKernelGGL(k_mf_active, dim3(std::min(cdiv(d.P, 256 * 4), 128), n_cur), dim3(256), 0, st, d, list_cur, ex, dist,
-                           active, tact_a, tiles_x, tiles_y);
-        hipLaunchKernelGGL(k_done_update, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, n_cur, list_cur, active, list_nxt, n_open);
-        GGC_LAUNCH_CHECK(ctx);
-        if ((rcode = read_i32(ctx, st, n_open, 1, host))) return rcode;
-        const int n_next = host[0];
-        if (trace) {   // diagnostics: active pixels / open images per round
-            std::vector<int32_t> act;
-            if ((rcode = read_i32(ctx, st, active, B, act))) return rcode;
-            long long tot = 0;
-            for (int v : act) tot += v;
-            std::fprintf(stderr, "[ggc maxflow] round %d: open images %d, active pixels %lld\n", round, n_next, tot);
-        }
-        if (n_next == 0) return GGC_OK;
-        std::swap(list_cur, list_nxt);
-        n_cur = n_next;
-        // ---- push-relabel sweeps
-        {
-            ProfScope prof(ctx, st, "maxflow_push");
-            int32_t *cur = tact_a, *nxt = tact_b;
-            // schedule measured on MI355X (tools/mf_sweep.sh): 24 launches x 8 sweeps per round, no shortened first round
-            static const int n_launch = [] { const char* e = std::getenv("GGC_MF_PR_LAUNCHES"); return e ? std::max(1, std::atoi(e)) : 24; }();
-            static const int n_inner = [] { const char* e = std::getenv("GGC_MF_PR_INNER"); return e ? std::max(1, std::atoi(e)) : 8; }();
-            // Optional shorter early rounds (GGC_MF_PR_FIRST << round launches); measured slower than a flat
-            // schedule because every extra round pays a full global relabel, so it is off by default.
-            static const int n_first = [] { const char* e = std::getenv("GGC_MF_PR_FIRST"); return e ? std::max(1, std::atoi(e)) : 4096; }();
-            const int launches_now = std::min(n_launch, n_first << std::min(round, 8));
-            const dim3 tiles(tiles_x, tiles_y, n_cur);
-            for (int l = 0; l < launches_now; ++l) {
-                hipLaunchKernelGGL(k_mf_pr_tile, tiles, dim3(256), 0, st, d, n_inner, list_cur, rc, ex, snk, dist, cur, nxt);
-                std::swap(cur, nxt);
-            }
-            GGC_LAUNCH_CHECK(ctx);
-        }
-    }
-    return set_err(ctx, GGC_E_DEVICE, "max-flow did not converge in %d rounds", max_rounds);
 }
 
 } // namespace ggc
@@ -878,7 +486,7 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
     GcDims d{B, H, W, H * W, cdiv((size_t)H * W, CHUNK)};
     const size_t BP = (size_t)B * d.P;
 
-    int32_t* small = scratch_t<int32_t>(ctx, S_GC_A, (size_t)B * 10 + 16);  // f1 | f2 | state | done | changed | active | n_open.. | err | open lists [2B]
+    int32_t* small = scratch_t<int32_t>(ctx, S_GC_A, (size_t)B * 8 + 32);   // f1 | f2 | state | - | max-flow flags [B+7] | err | open lists [2B]
     Gmm* gmm = scratch_t<Gmm>(ctx, S_GC_B, (size_t)B * 2);
     unsigned long long* acc = scratch_t<unsigned long long>(ctx, S_GC_C, (size_t)B * 2 * NCOMP * ACC_W + B);
     uint8_t* comp = scratch_t<uint8_t>(ctx, S_GC_D, BP);
@@ -889,10 +497,10 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
     if (!small || !gmm || !acc || !comp || !nw || !rc || !ex || !rmask) return GGC_E_OOM;
     int32_t* snk = ex + BP;
     int32_t* dist = ex + 2 * BP;
-    int32_t *f1 = small, *f2 = small + B, *state = small + 2 * B, *done = small + 3 * B, *mf_flags = small + 4 * B;
-    int32_t* err = small + 8 * B;
+    int32_t *f1 = small, *f2 = small + B, *state = small + 2 * B, *mf_flags = small + 4 * B;
+    int32_t* err = small + 6 * B + 8;
     unsigned long long* bsum = acc + (size_t)B * 2 * NCOMP * ACC_W;
-    GGC_HIP(ctx, hipMemsetAsync(small, 0, sizeof(int32_t) * ((size_t)B * 10 + 16), st));
+    GGC_HIP(ctx, hipMemsetAsync(small, 0, sizeof(int32_t) * ((size_t)B * 8 + 32), st));
     GGC_HIP(ctx, hipMemsetAsync(acc, 0, sizeof(unsigned long long) * ((size_t)B * 2 * NCOMP * ACC_W + B), st));
 
     if (mode == 1) {
@@ -945,7 +553,7 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                                    (warm_ok && it > 0) ? 1 : 0);
             }
             GGC_LAUNCH_CHECK(ctx);
-            int rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 8 * B + 16, mf_flags);
+            int rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 6 * B + 16, mf_flags);
             if (rcode) return rcode;
             hipLaunchKernelGGL(k_gc_relabel, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, state, dist, mask);
             GGC_LAUNCH_CHECK(ctx);

@@ -1,0 +1,369 @@
+// ggc_maxflow.hip — max-flow / min-cut for GrabCut (C5: GCGraph::maxFlow + the
+// source/sink labelling of estimateSegmentation) on the
+// implicit 8-neighbour pixel grid with int32 capacities, all images of a batch at once.
+//
+// Algorithm: lock-free push-relabel (Hong 2008) in rounds of
+//     global relabel  (exact BFS distances to the sink, as a min-plus relaxation)
+//     -> push-relabel sweeps
+// until no pixel holds excess that can still reach the sink.  Only phase 1
+// (maximum preflow) is needed: a pixel is foreground iff it cannot reach the sink
+// in the residual graph, which the last relabel has just computed.
+//
+// Mapping to the hardware:
+//  * both phases work on LDS-resident tiles.  Relabel: a 32x32 tile + halo of labels
+//    is relaxed to a local fixpoint per visit.  Push: a 32x8 tile of excess / residual
+//    capacities / labels runs `inner` sweeps with LDS atomics; pushes across the tile
+//    edge use global atomics, and the write-back applies DELTAS atomically because a
+//    neighbouring tile may have added to this tile's excess or reverse arcs meanwhile.
+//    Every stale value is a lower bound of the true one, which is the asynchrony the
+//    lock-free algorithm tolerates.
+//  * activity is sparse (about 1 % of the pixels after the first round, a handful of
+//    images in the last rounds), so every launch walks a WORK LIST of tiles instead of
+//    the whole grid: a tile that changes (relabel) or keeps / hands over excess (push)
+//    appends itself or its neighbour to the next list (flag + atomic counter), and a
+//    launch costs a few microseconds when there is little to do.  Three rotating
+//    counters let the launch that consumes list L also clear the counter of list L+2.
+//  * images without active pixels leave the open-image list; converged tiles cost nothing.
+#include "ggc_gc.h"
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+namespace ggc {
+
+constexpr int RT = 32;                 // relabel tile side
+constexpr int RT_ROWS = 256 / RT;      // tile rows covered by one pass of the 256 threads
+constexpr int RT_NJ = RT * RT / 256;   // pixels per thread
+constexpr int PT_W = 32, PT_H = 8;     // push tile
+static const int LIST_GRID = [] { const char* e = std::getenv("GGC_MF_LIST_GRID"); return e ? std::max(64, std::atoi(e)) : 8192; }();   // blocks per work-list launch
+
+struct MfTiles { int rt_x, rt_y, pt_x, pt_y; };   // tiles per image
+
+__device__ __forceinline__ int ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// append `tile` to the next work list unless it is already on it
+__device__ __forceinline__ void push_tile(int tile, int32_t* __restrict__ flag, int32_t* __restrict__ list,
+                                          int32_t* __restrict__ count) {
+    if (ld(&flag[tile]) == 0 && atomicExch(&flag[tile], 1) == 0) list[atomicAdd(count, 1)] = tile;   // cheap test first
+}
+
+// start of a global relabel: d = 1 next to the sink, infinity elsewhere; rmask bit dir = residual arc p -> nb(dir)
+__global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __restrict__ open_list, const int32_t* __restrict__ snk,
+                                                  const int32_t* __restrict__ rc, int32_t* __restrict__ dist,
+                                                  uint8_t* __restrict__ rmask) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t BP = (size_t)d.B * d.P;
+    if (p >= d.P) return;
+    const size_t i = (size_t)open_list[blockIdx.y] * d.P + p;
+    dist[i] = snk[i] > 0 ? 1 : DINF;
+    int m = 0;
+#pragma unroll
+    for (int dir = 0; dir < 8; ++dir) m |= (rc[(size_t)dir * BP + i] > 0) ? (1 << dir) : 0;
+    rmask[i] = (uint8_t)m;
+}
+
+// every relabel tile of every open image starts on the frontier
+__global__ void k_mf_list_all(int n_open, const int32_t* __restrict__ open_list, int tiles_per_image,
+                              int32_t* __restrict__ list, int32_t* __restrict__ flag, int32_t* __restrict__ counters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { counters[0] = n_open * tiles_per_image; counters[1] = 0; counters[2] = 0; }
+    if (i >= n_open * tiles_per_image) return;
+    const int tile = open_list[i / tiles_per_image] * tiles_per_image + i % tiles_per_image;
+    list[i] = tile;
+    flag[tile] = 1;
+}
+
+// Global relabel over a work list of 32x32 tiles.
+__global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int phase, const uint8_t* __restrict__ rmask,
+                                                       int32_t* __restrict__ dist, int32_t* __restrict__ counters,
+                                                       const int32_t* __restrict__ list_in, int32_t* __restrict__ list_out,
+                                                       int32_t* __restrict__ flag_in, int32_t* __restrict__ flag_out) {
+    __shared__ int sd[RT + 2][RT + 2];
+    const int tid = threadIdx.x;
+    const int n_in = counters[phase % 3];
+    int32_t* n_out = counters + (phase + 1) % 3;
+    if (blockIdx.x == 0 && tid == 0) counters[(phase + 2) % 3] = 0;       // the list after next starts empty
+    const int tiles_per_image = tl.rt_x * tl.rt_y;
+    const int lx = tid % RT;
+    for (int t = blockIdx.x; t < n_in; t += gridDim.x) {
+        const int tile = list_in[t];
+        const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
+        const int tyi = tr / tl.rt_x, txi = tr % tl.rt_x;
+        const int tx0 = txi * RT, ty0 = tyi * RT;
+        const size_t base = (size_t)b * d.P;
+        __syncthreads();                                                   // previous tile's LDS use is over
+        for (int i = tid; i < (RT + 2) * (RT + 2); i += 256) {
+            const int ly = i / (RT + 2), llx = i % (RT + 2);
+            const int gy = ty0 + ly - 1, gx = tx0 + llx - 1;
+            sd[ly][llx] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
+        }
+        int msk[RT_NJ], old[RT_NJ];
+#pragma unroll
+        for (int j = 0; j < RT_NJ; ++j) {
+            const int ly = (tid / RT) + RT_ROWS * j;
+            const int gy = ty0 + ly, gx = tx0 + lx;
+            msk[j] = (gx < d.W && gy < d.H) ? rmask[base + (size_t)gy * d.W + gx] : 0;
+        }
+        __syncthreads();
+        if (tid == 0) flag_in[tile] = 0;                                   // consumed
+#pragma unroll
+        for (int j = 0; j < RT_NJ; ++j) old[j] = sd[(tid / RT) + RT_ROWS * j + 1][lx + 1];
+        for (int it = 0; it < 4 * RT; ++it) {
+            int ch = 0;
+#pragma unroll
+            for (int j = 0; j < RT_NJ; ++j) {
+                if (!msk[j]) continue;
+                const int ly = (tid / RT) + RT_ROWS * j + 1, cx = lx + 1;
+                int nd = DINF;
+                if (msk[j] & 1) nd = min(nd, sd[ly][cx - 1]);
+                if (msk[j] & 2) nd = min(nd, sd[ly][cx + 1]);
+                if (msk[j] & 4) nd = min(nd, sd[ly - 1][cx]);
+                if (msk[j] & 8) nd = min(nd, sd[ly + 1][cx]);
+                if (msk[j] & 16) nd = min(nd, sd[ly - 1][cx - 1]);
+                if (msk[j] & 32) nd = min(nd, sd[ly + 1][cx + 1]);
+                if (msk[j] & 64) nd = min(nd, sd[ly - 1][cx + 1]);
+                if (msk[j] & 128) nd = min(nd, sd[ly + 1][cx - 1]);
+                if (nd < DINF && nd + 1 < sd[ly][cx]) { sd[ly][cx] = nd + 1; ch = 1; }
+            }
+            if (!__syncthreads_or(ch)) break;
+        }
+        int any = 0;
+#pragma unroll
+        for (int j = 0; j < RT_NJ; ++j) {
+            const int ly = (tid / RT) + RT_ROWS * j;
+            const int v = sd[ly + 1][lx + 1];
+            if (v != old[j]) { dist[base + (size_t)(ty0 + ly) * d.W + tx0 + lx] = v; any = 1; }
+        }
+        if (__syncthreads_or(any) && tid < 9) {                            // changed: this tile and its 8 neighbours go again
+            const int ty = tyi + tid / 3 - 1, tx = txi + tid % 3 - 1;
+            if (ty >= 0 && ty < tl.rt_y && tx >= 0 && tx < tl.rt_x)
+                push_tile(b * tiles_per_image + ty * tl.rt_x + tx, flag_out, list_out, n_out);
+        }
+    }
+}
+
+// Push-relabel sweeps over a work list of 32x8 tiles.
+__global__ void __launch_bounds__(256) k_mf_pr_list(GcDims d, MfTiles tl, int phase, int inner,
+                                                    int32_t* __restrict__ rc, int32_t* __restrict__ ex,
+                                                    int32_t* __restrict__ snk, int32_t* __restrict__ dist,
+                                                    int32_t* __restrict__ counters, const int32_t* __restrict__ list_in,
+                                                    int32_t* __restrict__ list_out, int32_t* __restrict__ flag_in,
+                                                    int32_t* __restrict__ flag_out) {
+    __shared__ int s_ex[256];
+    __shared__ int s_d[PT_H + 2][PT_W + 2];
+    __shared__ int s_rc[8][256];
+    const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
+    const int n_in = counters[phase % 3];
+    int32_t* n_out = counters + (phase + 1) % 3;
+    if (blockIdx.x == 0 && tid == 0) counters[(phase + 2) % 3] = 0;
+    const int tiles_per_image = tl.pt_x * tl.pt_y;
+    const size_t BP = (size_t)d.B * d.P;
+    for (int t = blockIdx.x; t < n_in; t += gridDim.x) {
+        const int tile = list_in[t];
+        const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
+        const int tyi = tr / tl.pt_x, txi = tr % tl.pt_x;
+        const int x = txi * PT_W + lx, y = tyi * PT_H + ly;
+        const bool inb = x < d.W && y < d.H;
+        const size_t base = (size_t)b * d.P;
+        const int p = y * d.W + x;
+        __syncthreads();
+        int e0 = 0, sk0 = 0, r0[8];
+        if (inb) { e0 = ex[base + p]; sk0 = snk[base + p]; }
+        s_ex[tid] = e0;
+#pragma unroll
+        for (int dir = 0; dir < 8; ++dir) { r0[dir] = inb ? rc[(size_t)dir * BP + base + p] : 0; s_rc[dir][tid] = r0[dir]; }
+        for (int i = tid; i < (PT_H + 2) * (PT_W + 2); i += 256) {
+            const int gy = tyi * PT_H + i / (PT_W + 2) - 1, gx = txi * PT_W + i % (PT_W + 2) - 1;
+            s_d[i / (PT_W + 2)][i % (PT_W + 2)] =
+                (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
+        }
+        __syncthreads();
+        if (tid == 0) flag_in[tile] = 0;                                   // consumed
+        const int d0 = s_d[ly + 1][lx + 1];
+        int sk = sk0;
+        for (int it = 0; it < inner; ++it) {
+            int act = 0;
+            if (inb) {
+                const int e = __hip_atomic_load(&s_ex[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int dp = s_d[ly + 1][lx + 1];
+                if (e > 0 && dp < d.P) {
+                    act = 1;
+                    int hmin = DINF, best = -1;
+                    if (sk > 0) { hmin = 0; best = 8; }
+#pragma unroll
+                    for (int dir = 0; dir < 8; ++dir)
+                        if (__hip_atomic_load(&s_rc[dir][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) {
+                            const int hq = s_d[ly + 1 + dir_dy(dir)][lx + 1 + dir_dx(dir)];
+                            if (hq < hmin) { hmin = hq; best = dir; }
+                        }
+                    if (best >= 0 && dp > hmin) {
+                        if (best == 8) {
+                            const int dl = min(e, sk);
+                            sk -= dl;
+                            atomicSub(&s_ex[tid], dl);
+                        } else {
+                            const int dl = min(e, __hip_atomic_load(&s_rc[best][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            atomicSub(&s_rc[best][tid], dl);
+                            atomicSub(&s_ex[tid], dl);
+                            const int bx = dir_dx(best), by = dir_dy(best);
+                            const int qlx = lx + bx, qly = ly + by;
+                            if (qlx >= 0 && qlx < PT_W && qly >= 0 && qly < PT_H) {
+                                const int qt = qly * PT_W + qlx;
+                                atomicAdd(&s_rc[best ^ 1][qt], dl);
+                                atomicAdd(&s_ex[qt], dl);
+                            } else {                                        // across the tile edge: straight to global memory
+                                const int q = p + by * d.W + bx;
+                                atomicAdd(&rc[(size_t)(best ^ 1) * BP + base + q], dl);
+                                atomicAdd(&ex[base + q], dl);
+                                push_tile(b * tiles_per_image + ((y + by) / PT_H) * tl.pt_x + (x + bx) / PT_W, flag_out, list_out, n_out);
+                            }
+                        }
+                    } else {
+                        s_d[ly + 1][lx + 1] = (best >= 0 && hmin < DINF) ? hmin + 1 : DINF;
+                    }
+                }
+            }
+            if (!__syncthreads_or(act)) break;
+        }
+        int left = 0;
+        if (inb) {
+            const int e1 = s_ex[tid];
+            if (e1 != e0) atomicAdd(&ex[base + p], e1 - e0);
+#pragma unroll
+            for (int dir = 0; dir < 8; ++dir) {
+                const int r1 = s_rc[dir][tid];
+                if (r1 != r0[dir]) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[dir]);
+            }
+            if (sk != sk0) snk[base + p] = sk;
+            const int d1 = s_d[ly + 1][lx + 1];
+            if (d1 != d0) dist[base + p] = d1;
+            left = (e1 > 0 && d1 < d.P) ? 1 : 0;
+        }
+        if (__syncthreads_or(left) && tid == 0) push_tile(tile, flag_out, list_out, n_out);   // still has work
+    }
+}
+
+// per image: number of pixels whose excess can still reach the sink; their push tiles form the round's first work list
+__global__ void __launch_bounds__(256) k_mf_active(GcDims d, MfTiles tl, const int32_t* __restrict__ open_list,
+                                                   const int32_t* __restrict__ ex, const int32_t* __restrict__ dist,
+                                                   int32_t* __restrict__ active, int32_t* __restrict__ flag,
+                                                   int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    const int b = open_list[blockIdx.y];
+    int n = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.P; p += gridDim.x * blockDim.x) {
+        const bool a = ex[(size_t)b * d.P + p] > 0 && dist[(size_t)b * d.P + p] < DINF;
+        if (a) {
+            const int y = p / d.W, x = p - y * d.W;
+            push_tile(b * tl.pt_x * tl.pt_y + (y / PT_H) * tl.pt_x + x / PT_W, flag, list, count);
+        }
+        n += a ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&active[b], n);
+}
+
+// closes images without active pixels and compacts the still-open ones into the next launch list
+__global__ void k_done_update(int n_cur, const int32_t* __restrict__ list_cur, const int32_t* __restrict__ active,
+                              int32_t* __restrict__ list_nxt, int32_t* __restrict__ n_open) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cur) return;
+    const int b = list_cur[i];
+    if (active[b] != 0) list_nxt[atomicAdd(n_open, 1)] = b;
+}
+__global__ void k_open_init(int B, const int32_t* __restrict__ state, int32_t* __restrict__ list, int32_t* __restrict__ n_open) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && !state[b]) list[atomicAdd(n_open, 1)] = b;
+}
+
+int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std::vector<int32_t>& host) {
+    host.resize(n);
+    GGC_HIP(ctx, hipMemcpyAsync(host.data(), dev, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    GGC_HIP(ctx, hipStreamSynchronize(st));
+    return GGC_OK;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::max(1, std::atoi(e)) : dflt;
+}
+
+int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
+            int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists /*[2B] open-image lists*/,
+            int32_t* flags /*[B] active | [1] n_open | [3] relabel counters | [3] push counters*/) {
+    const int B = d.B;
+    int32_t* active = flags;
+    int32_t* n_open = flags + B;
+    int32_t* rl_cnt = flags + B + 1;
+    int32_t* pr_cnt = flags + B + 4;
+    const MfTiles tl{cdiv(d.W, RT), cdiv(d.H, RT), cdiv(d.W, PT_W), cdiv(d.H, PT_H)};
+    const size_t n_rt = (size_t)tl.rt_x * tl.rt_y * B, n_pt = (size_t)tl.pt_x * tl.pt_y * B;
+    // per tile kind: two ping-pong work lists and two ping-pong membership flags
+    int32_t* rl = scratch_t<int32_t>(ctx, S_GC_N, n_rt * 4);
+    int32_t* pt = scratch_t<int32_t>(ctx, S_GC_M, n_pt * 4);
+    if (!rl || !pt) return GGC_E_OOM;
+    int32_t *rl_list[2] = {rl, rl + n_rt}, *rl_flag[2] = {rl + 2 * n_rt, rl + 3 * n_rt};
+    int32_t *pt_list[2] = {pt, pt + n_pt}, *pt_flag[2] = {pt + 2 * n_pt, pt + 3 * n_pt};
+    int32_t *list_cur = lists, *list_nxt = lists + B;
+    std::vector<int32_t> host;
+    GGC_HIP(ctx, hipMemsetAsync(n_open, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_open_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, list_cur, n_open);
+    GGC_LAUNCH_CHECK(ctx);
+    int rcode = read_i32(ctx, st, n_open, 1, host);
+    if (rcode) return rcode;
+    int n_cur = host[0];
+    if (n_cur == 0) return GGC_OK;
+    const bool trace = std::getenv("GGC_MF_TRACE") != nullptr;
+    // schedule measured on MI355X (tools/mf_sweep.sh)
+    static const int n_launch = env_int("GGC_MF_PR_LAUNCHES", 24), n_inner = env_int("GGC_MF_PR_INNER", 8);
+    const int max_rounds = 4096;
+    for (int round = 0; round < max_rounds; ++round) {
+        // ---- global relabel of the open images
+        {
+            ProfScope prof(ctx, st, "maxflow_relabel");
+            hipLaunchKernelGGL(k_mf_dinit, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
+            GGC_HIP(ctx, hipMemsetAsync(rl_flag[0], 0, sizeof(int32_t) * n_rt * 2, st));
+            const int per_image = tl.rt_x * tl.rt_y;
+            hipLaunchKernelGGL(k_mf_list_all, dim3(cdiv((size_t)n_cur * per_image, 256)), dim3(256), 0, st, n_cur, list_cur, per_image,
+                               rl_list[0], rl_flag[0], rl_cnt);
+            int phase = 0;
+            for (int guard = 0; guard < 100000; ++guard) {
+                for (int rep = 0; rep < 4; ++rep, ++phase)
+                    hipLaunchKernelGGL(k_mf_relax_list, dim3(LIST_GRID), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
+                                       rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
+                GGC_LAUNCH_CHECK(ctx);
+                if ((rcode = read_i32(ctx, st, rl_cnt + phase % 3, 1, host))) return rcode;   // size of the next frontier
+                if (host[0] == 0) break;
+            }
+        }
+        // ---- who still has work?  (active pixel = excess that can still reach the sink)
+        GGC_HIP(ctx, hipMemsetAsync(active, 0, sizeof(int32_t) * (B + 7), st));               // active, n_open, all counters
+        GGC_HIP(ctx, hipMemsetAsync(pt_flag[0], 0, sizeof(int32_t) * n_pt * 2, st));
+        hipLaunchKernelGGL(k_mf_active, dim3(std::min(cdiv(d.P, 256 * 4), 128), n_cur), dim3(256), 0, st, d, tl, list_cur, ex, dist,
+                           active, pt_flag[0], pt_list[0], pr_cnt);
+        hipLaunchKernelGGL(k_done_update, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, n_cur, list_cur, active, list_nxt, n_open);
+        GGC_LAUNCH_CHECK(ctx);
+        if ((rcode = read_i32(ctx, st, n_open, 1, host))) return rcode;
+        const int n_next = host[0];
+        if (trace) {   // diagnostics: active pixels / open images per round
+            std::vector<int32_t> act;
+            if ((rcode = read_i32(ctx, st, active, B, act))) return rcode;
+            long long tot = 0;
+            for (int v : act) tot += v;
+            std::fprintf(stderr, "[ggc maxflow] round %d: open images %d, active pixels %lld\n", round, n_next, tot);
+        }
+        if (n_next == 0) return GGC_OK;
+        std::swap(list_cur, list_nxt);
+        n_cur = n_next;
+        // ---- push-relabel sweeps
+        {
+            ProfScope prof(ctx, st, "maxflow_push");
+            for (int phase = 0; phase < n_launch; ++phase)
+                hipLaunchKernelGGL(k_mf_pr_list, dim3(LIST_GRID), dim3(256), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
+                                   pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
+            GGC_LAUNCH_CHECK(ctx);
+        }
+    }
+    return set_err(ctx, GGC_E_DEVICE, "max-flow did not converge in %d rounds", max_rounds);
+}
+
+} // namespace ggc
