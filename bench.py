@@ -177,7 +177,7 @@ def main() -> None:
         b_launch = agg_bytes(n_nodes, n_edges, HIDDEN, batch_size)
         achieved = b_launch / agg_avg_s / 1e9 if launches else 0.0
         roofline = {
-            "kernel": "k_aggregate<128,0> (GCNConv scatter-gather, fused gate/GELU/residual epilogue)",
+            "kernel": "k_aggregate_graph<128,0,32> (GCNConv scatter-gather, graph slice resident in LDS, fused gate/GELU/residual epilogue)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "bytes_per_launch": b_launch, "avg_launch_us": round(agg_avg_s * 1e6, 2), "launches": launches,

@@ -15,7 +15,7 @@ constexpr int WAVE = 64;
 
 // Scratch slots: one growing device buffer per slot, owned by the context.
 enum Slot : int {
-    S_CSR_ROWPTR = 0, S_CSR_COL, S_CSR_EID, S_CSR_CURSOR, S_DIS, S_BATCH,
+    S_CSR_ROWPTR = 0, S_CSR_COL, S_CSR_EID, S_CSR_CURSOR, S_DIS, S_BATCH, S_AGG_PACK,
     S_STATES, S_GATE, S_XW, S_AGG, S_SCORE, S_GVEC, S_HJK,
     S_PRE_A, S_PRE_B, S_PRE_C, S_PRE_D,
     S_SLIC_IMG, S_SLIC_TMP, S_SLIC_CENTERS, S_SLIC_DIST, S_SLIC_LABELS, S_SLIC_AUX,
@@ -136,8 +136,43 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// GELU(x) = x * Phi(x) (exact, erf-based form; reference model.py uses nn.GELU()).  The aggregation
+// epilogue is VALU-bound with libm's branchy erff (~100 instructions per value), so Phi comes from a
+// branch-free fit of our own: with t = |x| / sqrt(2), u = 1 / (1 + p t),
+//     erfc(t) ~= (a1 u + ... + a6 u^6) exp(-t^2),   |error| < 8e-9 on [0, 6.5]
+// (Lawson-weighted least squares against scipy.special.erfc; p = 0.39030933).  In f32 the absolute
+// error of GELU is 3.8e-7 on [-12, 12], the same as 0.5 x (1 + erff(x / sqrt 2)) evaluated in f32.
 __device__ __forceinline__ float gelu_f(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    const float u = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x), 0.27599036693573f, 1.0f));
+    float q = -0.11346635967493057f;                       // a_k / 2, highest power first
+    q = __builtin_fmaf(q, u, 0.44092419743537903f);
+    q = __builtin_fmaf(q, u, -0.3140281140804291f);
+    q = __builtin_fmaf(q, u, 0.3222678005695343f);
+    q = __builtin_fmaf(q, u, 0.04667610302567482f);
+    q = __builtin_fmaf(q, u, 0.1176263764500618f);
+    const float hq = (q * u) * __builtin_amdgcn_exp2f((x * x) * -0.7213475108146667f);   // erfc(|x|/sqrt 2) / 2
+    return x * (x >= 0.0f ? 1.0f - hq : hq);
+}
+// Four values at once on the packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32): same arithmetic as gelu_f.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f gelu4_f(v4f x) {
+    const v4f d = __builtin_elementwise_fma(__builtin_elementwise_abs(x), (v4f)0.27599036693573f, (v4f)1.0f);
+    v4f u;
+    u.x = __builtin_amdgcn_rcpf(d.x); u.y = __builtin_amdgcn_rcpf(d.y); u.z = __builtin_amdgcn_rcpf(d.z); u.w = __builtin_amdgcn_rcpf(d.w);
+    v4f q = -0.11346635967493057f;
+    q = __builtin_elementwise_fma(q, u, (v4f)0.44092419743537903f);
+    q = __builtin_elementwise_fma(q, u, (v4f)-0.3140281140804291f);
+    q = __builtin_elementwise_fma(q, u, (v4f)0.3222678005695343f);
+    q = __builtin_elementwise_fma(q, u, (v4f)0.04667610302567482f);
+    q = __builtin_elementwise_fma(q, u, (v4f)0.1176263764500618f);
+    const v4f t = (x * x) * -0.7213475108146667f;
+    v4f e;
+    e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y); e.z = __builtin_amdgcn_exp2f(t.z); e.w = __builtin_amdgcn_exp2f(t.w);
+    const v4f hq = (q * u) * e, om = 1.0f - hq;
+    v4f phi;
+    phi.x = x.x >= 0.0f ? om.x : hq.x; phi.y = x.y >= 0.0f ? om.y : hq.y;
+    phi.z = x.z >= 0.0f ? om.z : hq.z; phi.w = x.w >= 0.0f ? om.w : hq.w;
+    return x * phi;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 

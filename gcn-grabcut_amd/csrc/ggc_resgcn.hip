@@ -19,6 +19,7 @@
 // built once per forward, stable in edge order, and reused by all 8 gathers.
 #include "ggc_internal.h"
 #include <cmath>
+#include <type_traits>
 
 namespace ggc {
 
@@ -504,95 +505,241 @@ __global__ void __launch_bounds__(1024) k_aggregate(int N, const float* __restri
     if (rvalid && cvalid) reinterpret_cast<float4*>(out)[o4] = acc;
 }
 
-// LDS-windowed form of the gather.  PMC profiling of the kernel above shows ideal HBM traffic
-// (FETCH+WRITE == algorithmic bytes) but the per-CU L1/texture path ~76 % busy: every neighbour row
-// costs a 16-cycle slot of the 64 B/clk vector-memory pipe.  About half of the edges are region
-// adjacencies whose endpoints are a few dozen node ids apart (superpixels are numbered in raster
-// order), so a block that owns S consecutive rows first copies the window [s0-HALO, s0+S+HALO) of xw
-// into LDS with fully coalesced loads and then serves every neighbour inside the window — and the
-// self loop — by ds_read_b128, which runs on the separate 256 B/clk LDS pipe.  Only the non-local
-// colour edges still go to L2.  Arithmetic and summation order are unchanged.
-template <int D> struct AggLds {
-    static constexpr int S = 96, HALO = 32, WIN = S + 2 * HALO;
-    static constexpr size_t BYTES = (size_t)WIN * D * sizeof(float);
+// Graph-resident form of the gather (the one the forward pass uses).  PMC profiling of the kernel
+// above shows ideal HBM traffic (FETCH+WRITE == algorithmic bytes) but the per-CU L1/texture path
+// ~76 % busy and two thirds of the L2 requests being re-reads: every neighbour row costs a 16-cycle
+// slot of the 64 B/clk vector-memory pipe.  The graphs of a batch are independent and small (about
+// 600 superpixels), so a block owns ONE graph and a SW-float column slice of the feature matrix:
+// it copies its [n_g, SW] slice of xw (and the graph's dis) into LDS once by LDS-DMA (128-B segments,
+// every byte of xw is read from memory exactly once) and then serves every neighbour row and the
+// self loop by ds_read_b128 on the 256 B/clk LDS pipe.  Two blocks share a CU (80 KiB each), so one
+// block's fill overlaps the other's gather.  The D/SW slices of one graph run on the same XCD and
+// share the CSR through its L2.  A graph with more than CAP nodes, or an edge that leaves its graph,
+// falls back to global loads per block / per row.  Arithmetic and summation order are those of
+// k_aggregate.
+constexpr int AGG_GRAPH_LDS = 80 * 1024;
+
+template <int SW> struct AggGraph {
+    static constexpr int LPR = SW / 4, RPW = 64 / LPR, RPP = 8 * RPW;          // 8 waves: rows per pass of the block
+    static constexpr int CAP_LDS = (AGG_GRAPH_LDS - SW * 4 - 4) / (SW * 4 + 4) ;   // tile row + dis entry, one zero row
+    static constexpr int CAP = CAP_LDS < 1023 ? CAP_LDS : 1023;                // 10-bit row offsets in the packed columns
+    static constexpr int K = (CAP + RPP - 1) / RPP;                            // passes for a full tile
+    static constexpr int FILL = (CAP * LPR + 511) / 512;                       // LDS-DMA pieces per thread
 };
 
-template <int D, int MODE>
-__global__ void __launch_bounds__(512) k_aggregate_lds(int N, const float* __restrict__ xw,
-                                                       const int32_t* __restrict__ row_ptr,
-                                                       const int32_t* __restrict__ col,
-                                                       const float* __restrict__ dis,
-                                                       const float* __restrict__ bias,
-                                                       const float* __restrict__ gate,
-                                                       const float* __restrict__ h,
-                                                       float* __restrict__ out) {
-    constexpr int LPR = AggCfg<D>::LPR, RPW = AggCfg<D>::RPW, D4 = D / 4;
-    constexpr int S = AggLds<D>::S, HALO = AggLds<D>::HALO;
-    extern __shared__ float4 tile[];
+// broadcast lane U of every group of W lanes (W = 4 or 8): ds_swizzle, no address VGPR and no VALU
+template <int W, int U> __device__ __forceinline__ int group_bcast(int v) {
+    return __builtin_amdgcn_ds_swizzle(v, (0x1f & ~(W - 1)) | (U << 5));
+}
+template <int W, int U> __device__ __forceinline__ float group_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (0x1f & ~(W - 1)) | (U << 5)));
+}
+template <int W, int U0, int NU, typename F> __device__ __forceinline__ void unroll_bcast(F&& f) {
+    if constexpr (NU > 0) { f(std::integral_constant<int, U0>{}); unroll_bcast<W, U0 + 1, NU - 1>(f); }
+}
+
+// Per (row, lane) column words of the graph-resident gather, built once per forward pass and shared by
+// every layer (7 aggregations read the same CSR): for lane sl of the LPR lanes that own a row,
+//   bits 0-9 / 10-19: tile row (offset inside the graph) of neighbours sl and LPR + sl, ZROW when there is none
+//   bits 20+        : n + 1, or 0 for an irregular row (more than 2 * LPR neighbours, or an edge that leaves
+//                     the graph) which the kernel handles by the generic route
+// One coalesced load per row replaces the dependent row_ptr -> col hops in the gather kernel.
+template <int SW>
+__global__ void __launch_bounds__(256) k_agg_pack(int N, const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ batch,
+                                                  const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                                  int32_t* __restrict__ pack) {
+    constexpr int LPR = AggGraph<SW>::LPR, ZROW = AggGraph<SW>::CAP;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // N * LPR is a multiple of LPR: whole groups stay together
+    const int row = min(i / LPR, N - 1), sl = i % LPR;
+    const int g = batch[row];
+    const int g0 = node_ptr[g], n_g = node_ptr[g + 1] - g0;
+    const int beg = row_ptr[row], n = row_ptr[row + 1] - beg;
+    bool regular = n <= 2 * LPR;
+    int pk = 0;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const bool have = nb * LPR + sl < n;
+        const int off = have ? col[beg + nb * LPR + sl] - g0 : 0;
+        regular = regular && (unsigned)off < (unsigned)n_g;
+        pk |= (have ? off & 1023 : ZROW) << (10 * nb);
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) regular = regular && __shfl_xor((int)regular, o, LPR);
+    if (i < N * LPR) pack[i] = regular ? pk | (n + 1) << 20 : (ZROW | ZROW << 10);
+}
+
+// One row of the column slice by the generic route (columns, weights and out-of-tile rows from global memory).
+template <int D, int MODE, int SW>
+__device__ __forceinline__ void agg_row_generic(int row, int g0, int n_g, const float4* tile, const float4* __restrict__ xw4g,
+                                                const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                                const float* __restrict__ dis, const float4& bias4,
+                                                const float* __restrict__ gate, const float* __restrict__ h,
+                                                float* __restrict__ out, int s, int sl) {
+    constexpr int LPR = SW / 4, D4 = D / 4;
+    const int beg = row_ptr[row], end = row_ptr[row + 1];
+    const float di = (MODE == 0) ? dis[row] : 1.0f;
+    const size_t o4 = (size_t)row * D4 + s * LPR + sl;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = beg; base < end; base += LPR) {
+        const int m = min(LPR, end - base);
+        int c = g0;
+        float w = 0.0f;
+        if (sl < m) { c = col[base + sl]; if (MODE == 0) w = dis[c] * di; }
+        for (int u = 0; u < m; ++u) {
+            const int j = __shfl(c, u, LPR);
+            const float wu = __shfl(w, u, LPR);
+            const int off = j - g0;
+            const float4 v = (tile && (unsigned)off < (unsigned)n_g) ? tile[off * LPR + sl] : xw4g[(size_t)j * D4 + sl];
+            if (MODE == 0) fma4(acc, wu, v);
+            else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        }
+    }
+    if (MODE == 0) {
+        fma4(acc, di * di, tile ? tile[(row - g0) * LPR + sl] : xw4g[(size_t)row * D4 + sl]);
+        acc.x += bias4.x; acc.y += bias4.y; acc.z += bias4.z; acc.w += bias4.w;
+        if (gate) {
+            const float4 gt = reinterpret_cast<const float4*>(gate)[o4], hv = reinterpret_cast<const float4*>(h)[o4];
+            acc.x = hv.x + gelu_f(acc.x * gt.x); acc.y = hv.y + gelu_f(acc.y * gt.y);
+            acc.z = hv.z + gelu_f(acc.z * gt.z); acc.w = hv.w + gelu_f(acc.w * gt.w);
+        }
+    } else {
+        const int cnt = end - beg;
+        const float cf = (float)(cnt > 0 ? cnt : 1);
+        acc.x /= cf; acc.y /= cf; acc.z /= cf; acc.w /= cf;
+    }
+    reinterpret_cast<float4*>(out)[o4] = acc;
+}
+
+template <int D, int MODE, int SW, bool GATED>
+__global__ void __launch_bounds__(512, 4) k_aggregate_graph(int G, const int32_t* __restrict__ node_ptr,
+                                                            const float* __restrict__ xw,
+                                                            const int32_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ col,
+                                                            const int32_t* __restrict__ pack,
+                                                            const float* __restrict__ dis,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ gate,
+                                                            const float* __restrict__ h,
+                                                            float* __restrict__ out) {
+    using C = AggGraph<SW>;
+    constexpr int LPR = C::LPR, RPW = C::RPW, RPP = C::RPP, CAP = C::CAP, K = C::K, FILL = C::FILL, NS = D / SW, D4 = D / 4;
+    constexpr int NB = 2;                                  // column batches kept in registers (NB * LPR neighbours)
+    constexpr int PF = 3;                                  // epilogue rows kept in flight ahead of the gather
+    constexpr int ZROW = CAP;                              // all-zero tile row (and dis entry) the padding lanes point at
+    static_assert(D % SW == 0, "slice width must divide D");
+    static_assert(!GATED || MODE == 0, "the gated epilogue belongs to GCNConv");
+    extern __shared__ float4 tile[];                       // [CAP + 1][LPR] float4, then dis_l[CAP + 1]
+    float* dis_l = reinterpret_cast<float*>(tile + (CAP + 1) * LPR);
+    const v4f* tile4 = reinterpret_cast<const v4f*>(tile);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane / LPR, sl = lane % LPR;
-    const int blk = xcd_remap(blockIdx.x, gridDim.x);
-    const int s0 = blk * S;
-    const int w0 = max(s0 - HALO, 0), w1 = min(s0 + S + HALO, N);
-    const int nwin = w1 - w0;
-    const float4* xw4g = reinterpret_cast<const float4*>(xw);
-    for (int i = tid; i < nwin * D4; i += 512) tile[i] = xw4g[(size_t)w0 * D4 + i];
+    const int s = ((int)blockIdx.x >> 3) % NS;                                  // blocks b, b+8, ... share an XCD
+    const int g = ((int)blockIdx.x / (8 * NS)) * 8 + ((int)blockIdx.x & 7);
+    if (g >= G) return;
+    const int g0 = node_ptr[g], n_g = node_ptr[g + 1] - g0;
+    if (n_g <= 0) return;
+    const float4* xw4g = reinterpret_cast<const float4*>(xw) + s * LPR;         // column slice
+    const v4f* gate4 = reinterpret_cast<const v4f*>(gate) + s * LPR + sl;
+    const v4f* h4 = reinterpret_cast<const v4f*>(h) + s * LPR + sl;
+    const int r0 = wave * RPW + sub;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 0 && bias) bias4 = reinterpret_cast<const float4*>(bias)[s * LPR + sl];
+    if (n_g > CAP) {                                       // graph larger than the tile: everything from global memory
+        for (int r = r0; r < n_g; r += RPP)
+            agg_row_generic<D, MODE, SW>(g0 + r, g0, n_g, nullptr, xw4g, row_ptr, col, dis, bias4, gate, h, out, s, sl);
+        return;
+    }
+    // ---- preamble: the packed column words of this block's rows (k_agg_pack) and the tile fill are independent
+    // loads, so the block waits for one memory round trip; the gather then touches LDS only.
+    int cp[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int r = r0 + k * RPP;
+        cp[k] = (r < n_g) ? pack[(size_t)(g0 + r) * LPR + sl] : (ZROW | ZROW << 10 | 1 << 20);
+    }
+    // tile + dis fill: LDS-DMA, no registers; a wave instruction writes 64 consecutive elements
+#pragma unroll
+    for (int f = 0; f < FILL; ++f) {
+        const int i = tid + f * 512;
+        if (i < n_g * LPR)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xw4g + (size_t)(g0 + i / LPR) * D4 + i % LPR),
+                                             (__attribute__((address_space(3))) void*)(tile + f * 512 + wave * 64), 16, 0, 0);
+    }
+    if (MODE == 0) {
+#pragma unroll
+        for (int f = 0; f < (CAP + 511) / 512; ++f) {
+            const int i = tid + f * 512;
+            if (i < n_g)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dis + g0 + i),
+                                                 (__attribute__((address_space(3))) void*)(dis_l + f * 512 + wave * 64), 4, 0, 0);
+        }
+    }
+    if (tid < LPR) tile[ZROW * LPR + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid == LPR) dis_l[ZROW] = 0.0f;
+    // The gated epilogue streams gate and h from HBM: PF rows ahead are kept in flight, unconditionally (row
+    // clamped into the graph) so that the main loop is straight-line code and its waits stay counted.
+    v4f gtq[K], hvq[K];
+    if (GATED) {
+#pragma unroll
+        for (int k = 0; k < PF && k < K; ++k) {
+            const size_t p4 = (size_t)(g0 + min(r0 + k * RPP, n_g - 1)) * D4;
+            gtq[k] = gate4[p4]; hvq[k] = h4[p4];
+        }
+    }
     __syncthreads();
-    const bool cvalid = sl * 4 < D;
-    const int slc = cvalid ? sl : 0;
-    for (int r = wave * RPW + sub; r < S; r += 8 * RPW) {
-        const int row = s0 + r;
-        const bool rvalid = row < N;
-        const int rowc = rvalid ? row : s0;
-        const int beg = rvalid ? row_ptr[rowc] : 0, end = rvalid ? row_ptr[rowc + 1] : 0;
-        const float di = (MODE == 0) ? dis[rowc] : 1.0f;
-        const size_t o4 = (size_t)rowc * D4 + slc;
-        float4 gt = make_float4(0.f, 0.f, 0.f, 0.f), hv = gt;
-        if (MODE == 0 && gate) { gt = reinterpret_cast<const float4*>(gate)[o4]; hv = reinterpret_cast<const float4*>(h)[o4]; }
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int base = beg; base < end; base += LPR) {
-            const int n = min(LPR, end - base);
-            int c = 0;
-            float w = 0.0f;
-            if (sl < n) { c = col[base + sl]; if (MODE == 0) w = dis[c] * di; }
-            for (int k = 0; k < n; k += 8) {
-                float4 v[8];
-                float wk[8];
+    // ---- gather: LDS only, no global load besides the epilogue prefetch; no predication either, a padding
+    // lane adds 0 * 0 from the zero row (acc starts at +0 and x + (+-0) == x, so the sum is unchanged)
+    bool irregular = false;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int kk = min(k + u, n - 1);
-                    const int j = __shfl(c, kk, LPR);
-                    wk[u] = __shfl(w, kk, LPR);
-                    if (k + u < n) {
-                        const int off = j - w0;
-                        v[u] = ((unsigned)off < (unsigned)nwin) ? tile[off * D4 + slc] : xw4g[(size_t)j * D4 + slc];
-                    }
-                }
+    for (int k = 0; k < K; ++k) {
+        if (k * RPP + wave * RPW < n_g) {                  // wave-uniform
+            const int r = r0 + k * RPP;
+            const bool valid = r < n_g;
+            const int rc = valid ? r : n_g - 1;
+            if (GATED && k + PF < K) {
+                const size_t p4 = (size_t)(g0 + min(r + PF * RPP, n_g - 1)) * D4;
+                gtq[k + PF] = gate4[p4]; hvq[k + PF] = h4[p4];
+            }
+            const float di = (MODE == 0) ? dis_l[rc] : 1.0f;
+            const int code = cp[k] >> 20;
+            const int n = code > 0 ? code - 1 : 0;
+            v4f acc = 0.0f;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (k + u < n) {
-                        if (MODE == 0) fma4(acc, wk[u], v[u]);
-                        else { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            for (int nb = 0; nb < NB; ++nb) {
+                if (nb == 0 || nb * LPR < n) {
+                    const int myoff = (cp[k] >> (10 * nb)) & 1023;
+                    const float myw = (MODE == 0) ? dis_l[myoff] * di : 0.0f;
+                    v4f v[LPR];
+                    float wk[LPR];
+                    unroll_bcast<LPR, 0, LPR>([&](auto u) {
+                        v[u] = tile4[group_bcast<LPR, u>(myoff) * LPR + sl];
+                        if (MODE == 0) wk[u] = group_bcast<LPR, u>(myw);
+                    });
+#pragma unroll
+                    for (int u = 0; u < LPR; ++u) {
+                        if (MODE == 0) acc += wk[u] * v[u];
+                        else acc += v[u];
                     }
                 }
             }
-        }
-        if (MODE == 0) {
-            fma4(acc, di * di, tile[(rowc - w0) * D4 + slc]);
-            if (bias) {
-                const float4 b = reinterpret_cast<const float4*>(bias)[slc];
-                acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+            if (MODE == 0) {
+                acc += (di * di) * tile4[rc * LPR + sl];
+                acc += (v4f){bias4.x, bias4.y, bias4.z, bias4.w};
+                if (GATED) acc = hvq[k] + gelu4_f(acc * gtq[k]);
+            } else {
+                acc /= (float)(n > 0 ? n : 1);
             }
-            if (gate) {
-                acc.x = hv.x + gelu_f(acc.x * gt.x); acc.y = hv.y + gelu_f(acc.y * gt.y);
-                acc.z = hv.z + gelu_f(acc.z * gt.z); acc.w = hv.w + gelu_f(acc.w * gt.w);
-            }
-        } else {
-            const int cnt = end - beg;
-            const float cf = (float)(cnt > 0 ? cnt : 1);
-            acc.x /= cf; acc.y /= cf; acc.z /= cf; acc.w /= cf;
+            if (valid && code > 0) reinterpret_cast<v4f*>(out)[(size_t)(g0 + r) * D4 + s * LPR + sl] = acc;
+            irregular = irregular || (valid && code == 0);
         }
-        if (rvalid && cvalid) reinterpret_cast<float4*>(out)[o4] = acc;
+    }
+    if (__any(irregular)) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int r = r0 + k * RPP;
+            if (r < n_g && (cp[k] >> 20) == 0)
+                agg_row_generic<D, MODE, SW>(g0 + r, g0, n_g, tile, xw4g, row_ptr, col, dis, bias4, GATED ? gate : nullptr, h, out, s, sl);
+        }
     }
 }
 
@@ -818,26 +965,69 @@ static int launch_gemm(ggc_ctx* ctx, hipStream_t st, int N, const GemmArgs& a) {
     return GGC_OK;
 }
 
+template <int D, int MODE, int SW, bool GATED>
+static int launch_aggregate_graph_t(ggc_ctx* ctx, hipStream_t st, int G, const int32_t* node_ptr, const int32_t* pack,
+                                    const float* xw, const int32_t* row_ptr, const int32_t* col, const float* dis,
+                                    const float* bias, const float* gate, const float* h, float* out) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate_graph<D, MODE, SW, GATED>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, AGG_GRAPH_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_aggregate_graph<D, MODE, SW, GATED>), dim3(cdiv(G, 8) * 8 * (D / SW)), dim3(512), AGG_GRAPH_LDS, st,
+                       G, node_ptr, xw, row_ptr, col, pack, dis, bias, gate, h, out);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
+
+// Column-slice width of the graph-resident gather for G graphs with N nodes in total: the widest slice whose
+// [nodes-per-graph, SW] tile fits half a CU's LDS with a little head-room over the mean graph size (a larger
+// graph falls back per block); 0 = use the direct gather.
+static int agg_graph_slice(int N, int G) {
+    static const bool direct_only = [] { const char* e = std::getenv("GGC_AGG_DIRECT"); return e && e[0] == '1'; }();
+    if (G <= 0 || direct_only) return 0;
+    const double want = 1.02 * (double)N / G;
+    return want <= AggGraph<32>::CAP ? 32 : want <= AggGraph<16>::CAP ? 16 : 0;
+}
+
+// The forward pass hands over the batch structure (G graphs, node_ptr) and the packed column words built by
+// build_agg_pack for the slice width agg_graph_slice chose; without them (ggc_gcn_aggregate) the direct gather runs.
+struct AggGraphs { int G = 0, sw = 0; const int32_t* node_ptr = nullptr; const int32_t* pack = nullptr; };
+
+static int build_agg_pack(ggc_ctx* ctx, hipStream_t st, int N, int G, const int32_t* node_ptr, const int32_t* batch,
+                          const int32_t* row_ptr, const int32_t* col, AggGraphs& ag) {
+    ag = AggGraphs{};
+    const int sw = agg_graph_slice(N, G);
+    if (!sw || N <= 0) return GGC_OK;
+    const int lpr = sw / 4;
+    int32_t* pack = scratch_t<int32_t>(ctx, S_AGG_PACK, (size_t)N * lpr);
+    if (!pack) return GGC_E_OOM;
+    if (sw == 32) hipLaunchKernelGGL(k_agg_pack<32>, dim3(cdiv(N * lpr, 256)), dim3(256), 0, st, N, node_ptr, batch, row_ptr, col, pack);
+    else          hipLaunchKernelGGL(k_agg_pack<16>, dim3(cdiv(N * lpr, 256)), dim3(256), 0, st, N, node_ptr, batch, row_ptr, col, pack);
+    GGC_LAUNCH_CHECK(ctx);
+    ag.G = G; ag.sw = sw; ag.node_ptr = node_ptr; ag.pack = pack;
+    return GGC_OK;
+}
+
+template <int D, int MODE, int SW>
+static int launch_aggregate_graph(ggc_ctx* ctx, hipStream_t st, const AggGraphs& ag, const float* xw,
+                                  const int32_t* row_ptr, const int32_t* col, const float* dis, const float* bias,
+                                  const float* gate, const float* h, float* out) {
+    if constexpr (MODE == 0) {
+        if (gate)
+            return launch_aggregate_graph_t<D, MODE, SW, true>(ctx, st, ag.G, ag.node_ptr, ag.pack, xw, row_ptr, col, dis, bias, gate, h, out);
+    }
+    return launch_aggregate_graph_t<D, MODE, SW, false>(ctx, st, ag.G, ag.node_ptr, ag.pack, xw, row_ptr, col, dis, bias, nullptr, nullptr, out);
+}
+
 template <int D, int MODE>
 static int launch_aggregate(ggc_ctx* ctx, hipStream_t st, int N, const float* xw, const int32_t* row_ptr,
                             const int32_t* col, const float* dis, const float* bias, const float* gate,
-                            const float* h, float* out) {
+                            const float* h, float* out, const AggGraphs& ag = AggGraphs{}) {
     ProfScope prof(ctx, st, MODE == 0 ? "gcn_aggregate" : "sage_aggregate");
-    // A/B switch: the LDS-windowed variant is bit-identical but currently slower (127 vs 94 us at batch 256:
-    // the window fill is not overlapped with the gather yet), so the direct L2 gather stays the default.
-    static const bool use_lds = [] { const char* e = std::getenv("GGC_AGG_LDS"); return e && e[0] == '1'; }();
-    if (use_lds) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate_lds<D, MODE>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)AggLds<D>::BYTES));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((k_aggregate_lds<D, MODE>), dim3(cdiv(N, AggLds<D>::S)), dim3(512), AggLds<D>::BYTES, st,
-                           N, xw, row_ptr, col, dis, bias, gate, h, out);
-        GGC_LAUNCH_CHECK(ctx);
-        return GGC_OK;
-    }
+    if (ag.sw == 32) return launch_aggregate_graph<D, MODE, 32>(ctx, st, ag, xw, row_ptr, col, dis, bias, gate, h, out);
+    if (ag.sw == 16) return launch_aggregate_graph<D, MODE, 16>(ctx, st, ag, xw, row_ptr, col, dis, bias, gate, h, out);
     static const int threads = [] { const char* e = std::getenv("GGC_AGG_THREADS"); const int t = e ? std::atoi(e) : 256;
                                     return (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) ? t : 256; }();
     const int rows_per_block = AggCfg<D>::RPW * (threads / 64);
@@ -875,6 +1065,8 @@ static int forward_t(ggc_ctx* ctx, hipStream_t st, int G, int N, int E, const fl
     if (rc) return rc;
     hipLaunchKernelGGL(k_fill_batch, dim3(min(cdiv(N, 256), 4096)), dim3(256), 0, st, G, N, node_ptr, batch);
     GGC_LAUNCH_CHECK(ctx);
+    AggGraphs ag;
+    if ((rc = build_agg_pack(ctx, st, N, G, node_ptr, batch, row_ptr, col, ag))) return rc;
 
     const int wave_blocks = min(cdiv(N, 4), 8 * ctx->n_cu);
     {
@@ -906,12 +1098,12 @@ static int forward_t(ggc_ctx* ctx, hipStream_t st, int G, int N, int E, const fl
         a.out = xw;
         if ((rc = launch_gemm<D, 0>(ctx, st, N, a))) return rc;
         if ((rc = launch_aggregate<D, 0>(ctx, st, N, xw, row_ptr, col, dis, devp(ctx, "gcn_layers." + s + ".bias"),
-                                         gate, h_in, h_out)))
+                                         gate, h_in, h_out, ag)))
             return rc;
     }
     {
         const float* hl = states + ND * n;
-        if ((rc = launch_aggregate<D, 1>(ctx, st, N, hl, row_ptr, col, nullptr, nullptr, nullptr, nullptr, agg)))
+        if ((rc = launch_aggregate<D, 1>(ctx, st, N, hl, row_ptr, col, nullptr, nullptr, nullptr, nullptr, agg, ag)))
             return rc;
         GemmArgs a{};
         a.A1 = agg; a.A2 = hl;
