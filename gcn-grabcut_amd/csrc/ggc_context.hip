@@ -65,6 +65,8 @@ int ggc_ctx_create(int device_id, ggc_ctx** out) {
     if (!c) return ggc::set_err(nullptr, GGC_E_OOM, "host allocation failed");
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), sizeof(int32_t) * ggc_ctx::H_PINNED_INTS, hipHostMallocDefault) != hipSuccess)
+        c->h_pinned = nullptr;              // reads fall back to pageable memory
     *out = c;
     return GGC_OK;
 }
@@ -76,6 +78,7 @@ int ggc_ctx_destroy(ggc_ctx* ctx) {
     for (auto& r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& e : ctx->prof_pool) (void)hipEventDestroy(e);
     for (auto& b : ctx->slots) if (b.p) (void)hipFree(b.p);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (auto& kv : ctx->model.dev) if (kv.second.p) (void)hipFree(kv.second.p);
     delete ctx;
     return GGC_OK;

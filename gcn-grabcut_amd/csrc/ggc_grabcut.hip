@@ -486,7 +486,7 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
     GcDims d{B, H, W, H * W, cdiv((size_t)H * W, CHUNK)};
     const size_t BP = (size_t)B * d.P;
 
-    int32_t* small = scratch_t<int32_t>(ctx, S_GC_A, (size_t)B * 8 + 32);   // f1 | f2 | state | - | max-flow flags [B+7] | err | open lists [2B]
+    int32_t* small = scratch_t<int32_t>(ctx, S_GC_A, (size_t)B * 8 + 32);   // f1 | f2 | state | - | max-flow flags [B+8] | err | open lists [2B]
     Gmm* gmm = scratch_t<Gmm>(ctx, S_GC_B, (size_t)B * 2);
     unsigned long long* acc = scratch_t<unsigned long long>(ctx, S_GC_C, (size_t)B * 2 * NCOMP * ACC_W + B);
     uint8_t* comp = scratch_t<uint8_t>(ctx, S_GC_D, BP);

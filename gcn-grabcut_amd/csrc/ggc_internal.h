@@ -73,6 +73,8 @@ struct ggc_ctx {
     ggc::ResgcnWeights model;
     ggc::GraphState graph;
     int n_cu = 256;
+    int32_t* h_pinned = nullptr;           // page-locked staging for small device -> host reads (no pageable-copy stall)
+    static constexpr int H_PINNED_INTS = 4096;
 };
 
 namespace ggc {

@@ -26,6 +26,7 @@
 //  * images without active pixels leave the open-image list; converged tiles cost nothing.
 #include "ggc_gc.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <vector>
 
@@ -268,7 +269,7 @@ __global__ void k_done_update(int n_cur, const int32_t* __restrict__ list_cur, c
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cur) return;
     const int b = list_cur[i];
-    if (active[b] != 0) list_nxt[atomicAdd(n_open, 1)] = b;
+    if (active[b] != 0) { list_nxt[atomicAdd(n_open, 1)] = b; atomicAdd(n_open + 7, active[b]); }   // [7]: active pixels in total
 }
 __global__ void k_open_init(int B, const int32_t* __restrict__ state, int32_t* __restrict__ list, int32_t* __restrict__ n_open) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,6 +278,12 @@ __global__ void k_open_init(int B, const int32_t* __restrict__ state, int32_t* _
 
 int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std::vector<int32_t>& host) {
     host.resize(n);
+    if (ctx->h_pinned && n <= ggc_ctx::H_PINNED_INTS) {
+        GGC_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, dev, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+        GGC_HIP(ctx, hipStreamSynchronize(st));
+        std::copy(ctx->h_pinned, ctx->h_pinned + n, host.begin());
+        return GGC_OK;
+    }
     GGC_HIP(ctx, hipMemcpyAsync(host.data(), dev, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
     GGC_HIP(ctx, hipStreamSynchronize(st));
     return GGC_OK;
@@ -289,7 +296,7 @@ static int env_int(const char* name, int dflt) {
 
 int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
             int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists /*[2B] open-image lists*/,
-            int32_t* flags /*[B] active | [1] n_open | [3] relabel counters | [3] push counters*/) {
+            int32_t* flags /*[B] active | [1] n_open | [3] relabel counters | [3] push counters | [1] active total*/) {
     const int B = d.B;
     int32_t* active = flags;
     int32_t* n_open = flags + B;
@@ -315,9 +322,17 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     const bool trace = std::getenv("GGC_MF_TRACE") != nullptr;
     // schedule measured on MI355X (tools/mf_sweep.sh)
     static const int n_launch = env_int("GGC_MF_PR_LAUNCHES", 24), n_inner = env_int("GGC_MF_PR_INNER", 8);
+    static const int tail_active = env_int("GGC_MF_TAIL_ACTIVE", 4000), tail_launch = env_int("GGC_MF_TAIL_LAUNCHES", 64);
     const int max_rounds = 4096;
+    auto t_prev = std::chrono::steady_clock::now();
+    double push_ms = 0.0;
     for (int round = 0; round < max_rounds; ++round) {
+        // a launch over a work list costs ~20 us with LIST_GRID mostly empty blocks and ~6 us with a small grid, and the
+        // late rounds (a handful of open images) are pure launch latency: size the grids by what the open images can hold
+        const int rl_grid = (int)std::min<size_t>(LIST_GRID, std::max<size_t>(64, (size_t)n_cur * tl.rt_x * tl.rt_y));
+        const int pr_grid = (int)std::min<size_t>(LIST_GRID, std::max<size_t>(64, (size_t)n_cur * tl.pt_x * tl.pt_y / 2));
         // ---- global relabel of the open images
+        int relax_launches = 0;
         {
             ProfScope prof(ctx, st, "maxflow_relabel");
             hipLaunchKernelGGL(k_mf_dinit, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
@@ -328,28 +343,33 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             int phase = 0;
             for (int guard = 0; guard < 100000; ++guard) {
                 for (int rep = 0; rep < 4; ++rep, ++phase)
-                    hipLaunchKernelGGL(k_mf_relax_list, dim3(LIST_GRID), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
+                    hipLaunchKernelGGL(k_mf_relax_list, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
                                        rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
                 GGC_LAUNCH_CHECK(ctx);
+                relax_launches = phase;
                 if ((rcode = read_i32(ctx, st, rl_cnt + phase % 3, 1, host))) return rcode;   // size of the next frontier
                 if (host[0] == 0) break;
             }
         }
         // ---- who still has work?  (active pixel = excess that can still reach the sink)
-        GGC_HIP(ctx, hipMemsetAsync(active, 0, sizeof(int32_t) * (B + 7), st));               // active, n_open, all counters
+        GGC_HIP(ctx, hipMemsetAsync(active, 0, sizeof(int32_t) * (B + 8), st));               // active, n_open, all counters, total
         GGC_HIP(ctx, hipMemsetAsync(pt_flag[0], 0, sizeof(int32_t) * n_pt * 2, st));
         hipLaunchKernelGGL(k_mf_active, dim3(std::min(cdiv(d.P, 256 * 4), 128), n_cur), dim3(256), 0, st, d, tl, list_cur, ex, dist,
                            active, pt_flag[0], pt_list[0], pr_cnt);
         hipLaunchKernelGGL(k_done_update, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, n_cur, list_cur, active, list_nxt, n_open);
         GGC_LAUNCH_CHECK(ctx);
-        if ((rcode = read_i32(ctx, st, n_open, 1, host))) return rcode;
-        const int n_next = host[0];
+        if ((rcode = read_i32(ctx, st, n_open, 8, host))) return rcode;
+        const int n_next = host[0], total_active = host[7];
         if (trace) {   // diagnostics: active pixels / open images per round
             std::vector<int32_t> act;
             if ((rcode = read_i32(ctx, st, active, B, act))) return rcode;
             long long tot = 0;
             for (int v : act) tot += v;
-            std::fprintf(stderr, "[ggc maxflow] round %d: open images %d, active pixels %lld\n", round, n_next, tot);
+            const auto t_now = std::chrono::steady_clock::now();
+            const double ms = std::chrono::duration<double, std::milli>(t_now - t_prev).count();
+            std::fprintf(stderr, "[ggc maxflow] round %d: open images %d, active pixels %lld, relabel launches %d, relabel+scan %.3f ms, previous push %.3f ms\n",
+                         round, n_next, tot, relax_launches, ms - push_ms, push_ms);
+            t_prev = t_now;
         }
         if (n_next == 0) return GGC_OK;
         std::swap(list_cur, list_nxt);
@@ -357,10 +377,16 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
         // ---- push-relabel sweeps
         {
             ProfScope prof(ctx, st, "maxflow_push");
-            for (int phase = 0; phase < n_launch; ++phase)
-                hipLaunchKernelGGL(k_mf_pr_list, dim3(LIST_GRID), dim3(256), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
+            // few active pixels: their labels stay exact, so more (cheap) launches beat another global relabel
+            const int launches = total_active <= tail_active ? tail_launch : n_launch;
+            for (int phase = 0; phase < launches; ++phase)
+                hipLaunchKernelGGL(k_mf_pr_list, dim3(pr_grid), dim3(256), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
                                    pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
             GGC_LAUNCH_CHECK(ctx);
+            if (trace) {
+                GGC_HIP(ctx, hipStreamSynchronize(st));
+                push_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
+            }
         }
     }
     return set_err(ctx, GGC_E_DEVICE, "max-flow did not converge in %d rounds", max_rounds);

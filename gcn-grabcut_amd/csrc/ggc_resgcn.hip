@@ -513,15 +513,15 @@ __global__ void __launch_bounds__(1024) k_aggregate(int N, const float* __restri
 // it copies its [n_g, SW] slice of xw (and the graph's dis) into LDS once by LDS-DMA (128-B segments,
 // every byte of xw is read from memory exactly once) and then serves every neighbour row and the
 // self loop by ds_read_b128 on the 256 B/clk LDS pipe.  Two blocks share a CU (80 KiB each), so one
-// block's fill overlaps the other's gather.  The D/SW slices of one graph run on the same XCD and
+// block's fill overlaps the other's gather (three 52-KiB blocks with 16-float slices for larger graphs).  The D/SW slices of one graph run on the same XCD and
 // share the CSR through its L2.  A graph with more than CAP nodes, or an edge that leaves its graph,
 // falls back to global loads per block / per row.  Arithmetic and summation order are those of
 // k_aggregate.
-constexpr int AGG_GRAPH_LDS = 80 * 1024;
 
 template <int SW> struct AggGraph {
     static constexpr int LPR = SW / 4, RPW = 64 / LPR, RPP = 8 * RPW;          // 8 waves: rows per pass of the block
-    static constexpr int CAP_LDS = (AGG_GRAPH_LDS - SW * 4 - 4) / (SW * 4 + 4) ;   // tile row + dis entry, one zero row
+    static constexpr int LDS = (SW == 32 ? 80 : 52) * 1024;                    // 2 (SW 32) or 3 (SW 16) blocks per CU
+    static constexpr int CAP_LDS = (LDS - SW * 4 - 4) / (SW * 4 + 4);          // tile row + dis entry, one zero row
     static constexpr int CAP = CAP_LDS < 1023 ? CAP_LDS : 1023;                // 10-bit row offsets in the packed columns
     static constexpr int K = (CAP + RPP - 1) / RPP;                            // passes for a full tile
     static constexpr int FILL = (CAP * LPR + 511) / 512;                       // LDS-DMA pieces per thread
@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(512, 4) k_aggregate_graph(int G, const int32_t
     using C = AggGraph<SW>;
     constexpr int LPR = C::LPR, RPW = C::RPW, RPP = C::RPP, CAP = C::CAP, K = C::K, FILL = C::FILL, NS = D / SW, D4 = D / 4;
     constexpr int NB = 2;                                  // column batches kept in registers (NB * LPR neighbours)
-    constexpr int PF = 3;                                  // epilogue rows kept in flight ahead of the gather
+    constexpr int PF = 2;                                  // epilogue rows kept in flight ahead of the gather (1..3 measure alike, 4+ spills)
     constexpr int ZROW = CAP;                              // all-zero tile row (and dis entry) the padding lanes point at
     static_assert(D % SW == 0, "slice width must divide D");
     static_assert(!GATED || MODE == 0, "the gated epilogue belongs to GCNConv");
@@ -972,10 +972,10 @@ static int launch_aggregate_graph_t(ggc_ctx* ctx, hipStream_t st, int G, const i
     static bool attr_set = false;
     if (!attr_set) {
         GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate_graph<D, MODE, SW, GATED>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, AGG_GRAPH_LDS));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, AggGraph<SW>::LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_aggregate_graph<D, MODE, SW, GATED>), dim3(cdiv(G, 8) * 8 * (D / SW)), dim3(512), AGG_GRAPH_LDS, st,
+    hipLaunchKernelGGL((k_aggregate_graph<D, MODE, SW, GATED>), dim3(cdiv(G, 8) * 8 * (D / SW)), dim3(512), AggGraph<SW>::LDS, st,
                        G, node_ptr, xw, row_ptr, col, pack, dis, bias, gate, h, out);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
@@ -988,6 +988,8 @@ static int agg_graph_slice(int N, int G) {
     static const bool direct_only = [] { const char* e = std::getenv("GGC_AGG_DIRECT"); return e && e[0] == '1'; }();
     if (G <= 0 || direct_only) return 0;
     const double want = 1.02 * (double)N / G;
+    static const int force = [] { const char* e = std::getenv("GGC_AGG_SW"); return e ? std::atoi(e) : 0; }();
+    if (force == 16 && want <= AggGraph<16>::CAP) return 16;
     return want <= AggGraph<32>::CAP ? 32 : want <= AggGraph<16>::CAP ? 16 : 0;
 }
 

@@ -38,12 +38,62 @@ class DeviceGraphs:
 
 
 class Engine:
-    def __init__(self, device_index: int = 0):
+    def __init__(self, device_index: int = 0, private_context: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("gcn_grabcut needs an MI355X: no HIP device is visible and there is no CPU fallback")
         self.index = int(device_index)
         self.device = torch.device("cuda", self.index)
-        self.ctx = _native.get_context(self.index)
+        # a private context owns its scratch arena, so it can run concurrently with the shared one on another stream
+        self.ctx = _native.Context(self.index) if private_context else _native.get_context(self.index)
+        self._lanes = None
+
+    # ------------------------------------------------------------------ concurrent lanes
+    def lanes(self, n: int):
+        """n (engine, stream) pairs with private contexts for work that is independent per image.  GrabCut's
+        max-flow ends in rounds with a handful of open images that are pure launch latency; running sub-batches
+        on separate streams lets one sub-batch's tail overlap another's bandwidth-bound rounds."""
+        if self._lanes is None or len(self._lanes) != n:
+            self._pool = None
+            self._lanes = [(Engine(self.index, private_context=True), torch.cuda.Stream(self.device)) for _ in range(n)]
+        return self._lanes
+
+    def grabcut_lanes(self, image, mask, n_iter=5, mode=0, seed=0, n_lanes=4, bgd=None, fgd=None):
+        """grabcut() on n_lanes contiguous sub-batches at once; same results (image b keeps seed + b)."""
+        from concurrent.futures import ThreadPoolExecutor
+        b = image.size(0)
+        n_lanes = max(1, min(int(n_lanes), b))
+        if n_lanes == 1:
+            return self.grabcut(image, mask, n_iter, mode, None, seed, bgd, fgd)
+        bounds = [b * i // n_lanes for i in range(n_lanes + 1)]
+        if bgd is None:
+            bgd = torch.zeros(b, 65, dtype=torch.float64, device=self.device)
+        if fgd is None:
+            fgd = torch.zeros(b, 65, dtype=torch.float64, device=self.device)
+        binary = self.empty(b, *image.shape[1:3], dtype=torch.uint8)
+        caller = torch.cuda.current_stream(self.device)
+        lanes = self.lanes(n_lanes - 1)          # sub-batch 0 runs here, on the caller's stream and context
+
+        def run(i):
+            eng, stream = lanes[i - 1]
+            lo, hi = bounds[i], bounds[i + 1]
+            torch.cuda.set_device(self.device)
+            stream.wait_stream(caller)
+            with torch.cuda.stream(stream):
+                out = eng.grabcut(image[lo:hi], mask[lo:hi], n_iter, mode, None, seed + lo, bgd[lo:hi], fgd[lo:hi])
+                binary[lo:hi].copy_(out[0])
+            stream.synchronize()
+
+        if getattr(self, "_pool", None) is None or self._pool._max_workers != n_lanes - 1:
+            self._pool = ThreadPoolExecutor(max_workers=n_lanes - 1, thread_name_prefix="ggc-lane")
+        futures = [self._pool.submit(run, i) for i in range(1, n_lanes)]
+        out = self.grabcut(image[:bounds[1]], mask[:bounds[1]], n_iter, mode, None, seed, bgd[:bounds[1]], fgd[:bounds[1]])
+        binary[:bounds[1]].copy_(out[0])
+        for f in futures:
+            f.result()
+        return binary, mask, bgd, fgd
+
+    def all_contexts(self):
+        return [self.ctx] + [e.ctx for e, _ in (self._lanes or [])]
 
     # ------------------------------------------------------------------ helpers
     def _stream(self) -> int:

@@ -125,9 +125,10 @@ class GCNGrabCutPipeline:
     """
 
     def __init__(self, model, sp_config: Optional[SuperpixelGraphConfig] = None,
-                 gc_config: Optional[GrabCutConfig] = None, device: str = "cuda"):
+                 gc_config: Optional[GrabCutConfig] = None, device: str = "cuda", grabcut_lanes: int = 4):
         from ._engine import get_engine
         self._eng = get_engine(device)
+        self.grabcut_lanes = int(grabcut_lanes)   # additive: concurrent sub-batches of the GrabCut stage (batched calls only)
         self.model = model.to(self._eng.device)
         self.device = device
         self.sp_config = sp_config or SuperpixelGraphConfig()
@@ -170,9 +171,10 @@ class GCNGrabCutPipeline:
 
         t = tick()
         mask = trimap.clone()
-        binary, mask, bgd, fgd = eng.grabcut(bgr, mask, self.gc_config.n_iter, 0, None, self.gc_config.seed)
+        lanes = self.grabcut_lanes if bgr.size(0) >= 8 * max(self.grabcut_lanes, 1) else 1
+        binary, mask, bgd, fgd = eng.grabcut_lanes(bgr, mask, self.gc_config.n_iter, 0, self.gc_config.seed, lanes)
         if refine_iters > 0:
-            binary, mask, bgd, fgd = eng.grabcut(bgr, mask, refine_iters, 2, None, self.gc_config.seed, bgd, fgd)
+            binary, mask, bgd, fgd = eng.grabcut_lanes(bgr, mask, refine_iters, 2, self.gc_config.seed, lanes, bgd, fgd)
         if timing is not None:
             timing["grabcut"] = tick() - t
 
