@@ -228,12 +228,19 @@ __global__ void __launch_bounds__(256) k_mf_pr_list(GcDims d, MfTiles tl, int ph
         }
         int left = 0;
         if (inb) {
+            // only the tile's border ring can receive pushes from other tiles during this launch: the interior is
+            // owned exclusively, so its write-back is a plain store (L2 atomics are the scarce resource in the
+            // early rounds, when nearly every pixel changes)
+            const bool ring = lx == 0 || lx == PT_W - 1 || ly == 0 || ly == PT_H - 1;
             const int e1 = s_ex[tid];
-            if (e1 != e0) atomicAdd(&ex[base + p], e1 - e0);
+            if (e1 != e0) { if (ring) atomicAdd(&ex[base + p], e1 - e0); else ex[base + p] = e1; }
 #pragma unroll
             for (int dir = 0; dir < 8; ++dir) {
                 const int r1 = s_rc[dir][tid];
-                if (r1 != r0[dir]) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[dir]);
+                if (r1 != r0[dir]) {
+                    if (ring) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[dir]);
+                    else rc[(size_t)dir * BP + base + p] = r1;
+                }
             }
             if (sk != sk0) snk[base + p] = sk;
             const int d1 = s_d[ly + 1][lx + 1];

@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(512, 4) k_aggregate_graph(int G, const int32_t
     using C = AggGraph<SW>;
     constexpr int LPR = C::LPR, RPW = C::RPW, RPP = C::RPP, CAP = C::CAP, K = C::K, FILL = C::FILL, NS = D / SW, D4 = D / 4;
     constexpr int NB = 2;                                  // column batches kept in registers (NB * LPR neighbours)
-    constexpr int PF = 2;                                  // epilogue rows kept in flight ahead of the gather (1..3 measure alike, 4+ spills)
+    constexpr int PF = 2;                                  // epilogue rows kept in flight ahead of the gather (2 measured best; 4+ spills)
     constexpr int ZROW = CAP;                              // all-zero tile row (and dis entry) the padding lanes point at
     static_assert(D % SW == 0, "slice width must divide D");
     static_assert(!GATED || MODE == 0, "the gated epilogue belongs to GCNConv");
@@ -632,6 +632,7 @@ __global__ void __launch_bounds__(512, 4) k_aggregate_graph(int G, const int32_t
     float* dis_l = reinterpret_cast<float*>(tile + (CAP + 1) * LPR);
     const v4f* tile4 = reinterpret_cast<const v4f*>(tile);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);                    // tells the compiler it is wave-uniform
     const int sub = lane / LPR, sl = lane % LPR;
     const int s = ((int)blockIdx.x >> 3) % NS;                                  // blocks b, b+8, ... share an XCD
     const int g = ((int)blockIdx.x / (8 * NS)) * 8 + ((int)blockIdx.x & 7);
@@ -692,7 +693,8 @@ __global__ void __launch_bounds__(512, 4) k_aggregate_graph(int G, const int32_t
     bool irregular = false;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        if (k * RPP + wave * RPW < n_g) {                  // wave-uniform
+        if (k * RPP + wave_s * RPW >= n_g) break;          // scalar: no exec-masked region around the body, waits stay counted
+        {
             const int r = r0 + k * RPP;
             const bool valid = r < n_g;
             const int rc = valid ? r : n_g - 1;
