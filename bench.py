@@ -80,6 +80,20 @@ def agg_bytes(n_nodes: int, n_edges: int, d: int, n_graphs: int) -> int:
             + n_nodes * 4 + d * 4)
 
 
+def pmc_traffic(workload: str, batch: int):
+    """HBM bytes per launch of the graded kernel from the PMC counters.  Counters cannot be read from inside a
+    timed run (rocprofv3 --pmc serialises every dispatch), so this is the committed summary of the separate
+    FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/r01_pmc_bench_hbm.json, tools/pmc_bench.sh);
+    null for any other workload or batch size."""
+    if workload != "full" or batch != 256:
+        return None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench_hbm.json")) as fh:
+            return int(json.load(fh)["kernels"]["k_aggregate_graph<128, 0, 32, true>"]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,10 +199,11 @@ def main() -> None:
         b_launch = agg_bytes(n_nodes, n_edges, HIDDEN, batch_size)
         achieved = b_launch / agg_avg_s / 1e9 if launches else 0.0
         roofline = {
-            "kernel": "k_aggregate_graph<128,0,32> (GCNConv scatter-gather, graph slice resident in LDS, fused gate/GELU/residual epilogue)",
+            "kernel": "k_aggregate_graph<128,0,32,gated> (GCNConv scatter-gather, graph slice resident in LDS, fused gate/GELU/residual epilogue)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload, batch_size),
             "bytes_per_launch": b_launch, "avg_launch_us": round(agg_avg_s * 1e6, 2), "launches": launches,
+            "event_pair_overhead_us": round(ctx.profile_query("#event_pair_overhead")[1] * 1e3, 2),
         }
         stage_ms = {k: round(v[1] / args.steps, 3) for k, v in prof.items() if v[0]}
 

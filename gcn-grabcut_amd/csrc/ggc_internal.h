@@ -67,6 +67,7 @@ struct ggc_ctx {
     int device = 0;
     std::string err;
     bool prof_on = false;
+    double prof_overhead_ms = 0.0;         // duration an EMPTY event pair reports (calibrated at ggc_profile_enable)
     std::vector<ggc::ProfRec> prof;        // recorded scopes since ggc_profile_enable
     std::vector<hipEvent_t> prof_pool;     // recycled events
     ggc::Buf slots[ggc::S_COUNT];

@@ -67,7 +67,10 @@ const char* ggc_last_error(const ggc_ctx* ctx); /* ctx may be NULL: last create 
  * dominant kernels are bracketed by HIP events on their launch stream.
  * ggc_profile_enable(ctx, 1) clears earlier records and SYNCHRONISES the device;
  * ggc_profile_query sums the recorded durations of one kernel by name
- * ("gcn_aggregate", "gcn_gemm", "slic_assign", "maxflow", ...) and waits for them. */
+ * ("gcn_aggregate", "gcn_gemm", "slic_assign", "maxflow", ...) and waits for them.
+ * An event pair around nothing does not read zero (two queue packets), so enable
+ * calibrates that offset with empty pairs and query subtracts it per scope; the
+ * name "#event_pair_overhead" returns the offset itself (launches = 1). */
 int ggc_profile_enable(ggc_ctx* ctx, int on);
 int ggc_profile_query(ggc_ctx* ctx, const char* kernel, int* launches, double* total_ms);
 
