@@ -84,6 +84,79 @@ __global__ void __launch_bounds__(256) k_blur_v(TDims d, int n_planes, int radiu
     out[i] = (float)(s * scale);
 }
 
+// Both passes in one kernel for radius 1..8 (the pipeline uses 8): a block owns a 64 x 32 output tile of one plane,
+// stages the tile + halo in LDS (reflected coordinates applied at load), builds the f64 row sums of its 48 rows in
+// LDS and then the column sums.  Same taps in the same order as k_blur_h + k_blur_v — every sum is a fresh 2r+1-term
+// sum — so the result is bit-identical, but each plane is read and written once instead of crossing HBM as f64 row
+// sums in between (20 B/px -> 8 B/px, and no strided second pass).
+constexpr int BX_W = 64, BX_H = 32, BX_R = 8;
+
+template <int radius>
+__global__ void __launch_bounds__(256) k_box_fused(TDims d, const float* __restrict__ in, float* __restrict__ out) {
+    __shared__ float s_in[BX_H + 2 * radius][BX_W + 2 * radius + 1];
+    __shared__ double s_rs[BX_H + 2 * radius][BX_W];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * BX_W, ty0 = blockIdx.y * BX_H;
+    const size_t P = (size_t)d.H * d.W;
+    const float* src = in + (size_t)blockIdx.z * P;
+    constexpr int iw = BX_W + 2 * radius, ih = BX_H + 2 * radius;
+    for (int i = tid; i < ih * iw; i += 256) {
+        const int ly = i / iw, lx = i - ly * iw;
+        // rows / columns past the image edge are never used by an in-image output, clamp them into range first
+        const int gy = refl101(min(ty0 + ly - radius, d.H - 1 + radius), d.H);
+        const int gx = refl101(min(tx0 + lx - radius, d.W - 1 + radius), d.W);
+        s_in[ly][lx] = src[(size_t)gy * d.W + gx];
+    }
+    __syncthreads();
+    // row sums: 4 adjacent outputs per work item share their 2r+4 taps
+    for (int w = tid; w < ih * (BX_W / 4); w += 256) {
+        const int ly = w / (BX_W / 4), x4 = (w - ly * (BX_W / 4)) * 4;
+        double v[2 * radius + 4];
+#pragma unroll
+        for (int j = 0; j < 2 * radius + 4; ++j) v[j] = (double)s_in[ly][x4 + j];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            double sum = 0.0;
+#pragma unroll
+            for (int j = 0; j <= 2 * radius; ++j) sum += v[o + j];
+            s_rs[ly][x4 + o] = sum;
+        }
+    }
+    __syncthreads();
+    const int k = 2 * radius + 1;
+    const double scale = 1.0 / ((double)k * (double)k);
+    float* dst = out + (size_t)blockIdx.z * P;
+    // column sums: 8 adjacent rows of one column per work item
+    for (int w = tid; w < (BX_H / 8) * BX_W; w += 256) {
+        const int x = w % BX_W, y8 = (w / BX_W) * 8;
+        double v[2 * radius + 8];
+#pragma unroll
+        for (int j = 0; j < 2 * radius + 8; ++j) v[j] = s_rs[y8 + j][x];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            double sum = 0.0;
+#pragma unroll
+            for (int j = 0; j <= 2 * radius; ++j) sum += v[o + j];
+            const int gy = ty0 + y8 + o, gx = tx0 + x;
+            if (gy < d.H && gx < d.W) dst[(size_t)gy * d.W + gx] = (float)(sum * scale);
+        }
+    }
+}
+
+// box filter of n_planes [B][H*W] planes: fused for radius <= 8, the two HBM passes otherwise
+static void box_filter(hipStream_t st, const TDims& d, int n_planes, int radius, const float* in, double* hs, float* out) {
+    const size_t BP = (size_t)d.B * d.H * d.W;
+    const dim3 grid(cdiv(d.W, BX_W), cdiv(d.H, BX_H), d.B * n_planes);
+    switch ((size_t)d.B * n_planes <= 65535 ? radius : -1) {     // grid.z limit: very large batches take the two-pass route
+#define GGC_BOX(R) case R: hipLaunchKernelGGL(k_box_fused<R>, grid, dim3(256), 0, st, d, in, out); return;
+        GGC_BOX(1) GGC_BOX(2) GGC_BOX(3) GGC_BOX(4) GGC_BOX(5) GGC_BOX(6) GGC_BOX(7) GGC_BOX(8)
+#undef GGC_BOX
+        default: break;
+    }
+    hipLaunchKernelGGL(k_blur_h, dim3(cdiv(BP * n_planes, 256)), dim3(256), 0, st, d, n_planes, radius, in, hs);
+    hipLaunchKernelGGL(k_blur_v, dim3(cdiv(BP * n_planes, 256)), dim3(256), 0, st, d, n_planes, radius, hs, out);
+}
+
 // a = cov / (var + eps), b = mean_s - a * mean_g for BG and FG (4 planes)
 __global__ void __launch_bounds__(256) k_t_ab(size_t BP, float eps, const float* __restrict__ m /*6 planes*/,
                                               float* __restrict__ ab /*4 planes*/) {
@@ -237,12 +310,10 @@ extern "C" int ggc_refine_trimap(ggc_ctx* ctx, ggc_stream stream, int B, int H, 
     if (!planes || !hs || !means) return GGC_E_OOM;
     ProfScope prof(ctx, st, "refine_trimap");
     hipLaunchKernelGGL(k_t_prep, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, probs, node_ptr, segments, bgr, planes);
-    hipLaunchKernelGGL(k_blur_h, dim3(cdiv(BP * 6, 256)), dim3(256), 0, st, d, 6, radius, planes, hs);
-    hipLaunchKernelGGL(k_blur_v, dim3(cdiv(BP * 6, 256)), dim3(256), 0, st, d, 6, radius, hs, means);
+    box_filter(st, d, 6, radius, planes, hs, means);
     float* ab = planes + BP;                      // planes 1..4 are dead now; plane 0 (guide) stays
     hipLaunchKernelGGL(k_t_ab, dim3(cdiv(BP, 256)), dim3(256), 0, st, BP, eps, means, ab);
-    hipLaunchKernelGGL(k_blur_h, dim3(cdiv(BP * 4, 256)), dim3(256), 0, st, d, 4, radius, ab, hs);
-    hipLaunchKernelGGL(k_blur_v, dim3(cdiv(BP * 4, 256)), dim3(256), 0, st, d, 4, radius, hs, means);
+    box_filter(st, d, 4, radius, ab, hs, means);
     hipLaunchKernelGGL(k_t_final, dim3(cdiv(BP, 256)), dim3(256), 0, st, BP, threshold_fg, threshold_bg, planes, means,
                        trimap);
     GGC_LAUNCH_CHECK(ctx);
@@ -264,12 +335,10 @@ extern "C" int ggc_guided_filter(ggc_ctx* ctx, ggc_stream stream, int B, int H, 
     float* means = scratch_t<float>(ctx, S_T_C, BP * 6);
     if (!planes || !hs || !means) return GGC_E_OOM;
     hipLaunchKernelGGL(k_gf_prep, dim3(cdiv(BP, 256)), dim3(256), 0, st, BP, guide, src, planes);
-    hipLaunchKernelGGL(k_blur_h, dim3(cdiv(BP * 4, 256)), dim3(256), 0, st, d, 4, radius, planes, hs);
-    hipLaunchKernelGGL(k_blur_v, dim3(cdiv(BP * 4, 256)), dim3(256), 0, st, d, 4, radius, hs, means);
+    box_filter(st, d, 4, radius, planes, hs, means);
     float* ab = planes + BP;
     hipLaunchKernelGGL(k_gf_ab, dim3(cdiv(BP, 256)), dim3(256), 0, st, BP, eps, means, ab);
-    hipLaunchKernelGGL(k_blur_h, dim3(cdiv(BP * 2, 256)), dim3(256), 0, st, d, 2, radius, ab, hs);
-    hipLaunchKernelGGL(k_blur_v, dim3(cdiv(BP * 2, 256)), dim3(256), 0, st, d, 2, radius, hs, means);
+    box_filter(st, d, 2, radius, ab, hs, means);
     hipLaunchKernelGGL(k_gf_final, dim3(cdiv(BP, 256)), dim3(256), 0, st, BP, planes, means, out);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
