@@ -223,49 +223,93 @@ __global__ void __launch_bounds__(256) k_slic_assign(SlicGeom g, const float* __
     }
 }
 
-// One lane per cluster: float32 running sums over its pixels in raster order.
-// One WAVE per cluster.  The sums must be float32 running sums in raster order (that is what
-// skimage computes), so the additions stay sequential — but the memory side does not have to be:
-// the 64 lanes read 64 consecutive labels of a window row with one coalesced load, a ballot marks
-// the cluster's pixels, the matching lanes fetch their colours, and the wave then folds the set
-// bits in ascending lane (= x) order with v_readlane broadcasts.  Same additions, same order.
+// Centre update.  skimage accumulates float32 running sums over a cluster's pixels in raster order, so the
+// additions of the three colour channels must stay sequential per cluster — but nothing else has to:
+//  * a group of 16 lanes owns a cluster (4 clusters per wave, neighbours along the seed grid, so their windows
+//    and shapes are alike): the group reads a window row as 4 chunks of 16 consecutive labels, all four loads —
+//    and those of the next row — in flight together (the scan is otherwise a chain of L2 round trips), a ballot
+//    marks the cluster's pixels, the matching lanes fetch their colours;
+//  * the coordinate sums are sums of small integers: exact in float32 in any order while they stay below 2^24, so
+//    they are taken as integer popcount / lane-local sums (a cluster that large falls back to the ordered loop);
+//  * the colour fold walks the set bits of each group's ballot in ascending x with one ds_bpermute per channel,
+//    all four groups in the same wave instruction.  Same additions, same order, a quarter of the instructions.
+constexpr int UPD_LANES = 16, UPD_GROUPS = 64 / UPD_LANES, UPD_CH = 4;
+
 __global__ void __launch_bounds__(256) k_slic_update(SlicGeom g, const float* __restrict__ image,
                                                      const int32_t* __restrict__ labels,
                                                      const int32_t* __restrict__ stale,
                                                      float* __restrict__ centers, int4* __restrict__ bounds) {
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= g.K) return;
+    const int lane = threadIdx.x & 63, sub = lane / UPD_LANES, sl = lane % UPD_LANES;
+    const int k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * UPD_GROUPS + sub;
+    const bool live = k < g.K;
     const int b = blockIdx.y;
-    const size_t o = (size_t)b * g.K + k;
-    int4 bd = bounds[o];
-    if (stale[b]) bd = make_int4(0, g.H, 0, g.W);   // some pixel kept an old label: scan everything
+    const size_t o = (size_t)b * g.K + (live ? k : 0);
+    int4 bd = live ? bounds[o] : make_int4(0, 0, 0, 0);
+    if (live && stale[b]) bd = make_int4(0, g.H, 0, g.W);   // some pixel kept an old label: scan everything
     const size_t P = (size_t)g.H * g.W;
     const int32_t* lb = labels + (size_t)b * P;
     const float* im = image + (size_t)b * P * 3;
-    float sy = 0.f, sx = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    int cnt = 0;
-    for (int y = bd.x; y < bd.y; ++y) {
-        const size_t row = (size_t)y * g.W;
-        const float fy = (float)y;
-        for (int xc = bd.z; xc < bd.w; xc += 64) {
-            const int x = xc + lane;
-            const bool hit = x < bd.w && lb[row + x] == k;
-            unsigned long long bal = __ballot(hit);
-            if (!bal) continue;
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-            if (hit) { const float* px = im + (row + x) * 3; c0 = px[0]; c1 = px[1]; c2 = px[2]; }
-            cnt += __popcll(bal);
-            while (bal) {
-                const int l = __ffsll((long long)bal) - 1;
-                bal &= bal - 1;
-                sy += fy;
-                sx += (float)(xc + l);
-                s0 += __shfl(c0, l, 64); s1 += __shfl(c1, l, 64); s2 += __shfl(c2, l, 64);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    int cnt = 0, isy = 0, isx = 0;                          // isx: this lane's share, reduced at the end
+    const int rows = bd.y - bd.x, chunks = (bd.w - bd.z + UPD_LANES - 1) / UPD_LANES;
+    int rows_max = rows, chunks_max = chunks;               // the wave runs the longest of its four loops
+#pragma unroll
+    for (int off = UPD_LANES; off < 64; off <<= 1) {
+        rows_max = max(rows_max, __shfl_xor(rows_max, off, 64));
+        chunks_max = max(chunks_max, __shfl_xor(chunks_max, off, 64));
+    }
+    // labels of (row ry, chunks c0 .. c0 + UPD_CH - 1); -1 outside the group's window
+    auto load_row = [&](int ry, int c0, int (&lab)[UPD_CH]) {
+#pragma unroll
+        for (int c = 0; c < UPD_CH; ++c) {
+            const int x = bd.z + (c0 + c) * UPD_LANES + sl;
+            lab[c] = (ry < rows && x < bd.w) ? lb[(size_t)(bd.x + ry) * g.W + x] : -1;
+        }
+    };
+    // blocks of UPD_CH chunks in raster order: (row 0, block 0), (row 0, block 1), ..., (row 1, block 0), ...
+    const int nblk = (chunks_max + UPD_CH - 1) / UPD_CH, total = rows_max * nblk;
+    int cur[UPD_CH], nxt[UPD_CH];
+    if (total > 0) load_row(0, 0, cur);
+    int ry = 0, cb = 0;
+    for (int t = 0; t < total; ++t) {
+        int ry_n = ry, cb_n = cb + 1;
+        if (cb_n == nblk) { cb_n = 0; ++ry_n; }
+        load_row(ry_n, cb_n * UPD_CH, nxt);                 // next block in flight while this one is folded (row rows_max reads nothing)
+        const int y = bd.x + ry;
+#pragma unroll
+        for (int c = 0; c < UPD_CH; ++c) {
+            const bool hit = cur[c] == k && live;
+            const unsigned long long bal = __ballot(hit);
+            if (bal) {
+                const int x = bd.z + (cb * UPD_CH + c) * UPD_LANES + sl;
+                unsigned int m = (unsigned int)(bal >> (sub * UPD_LANES)) & 0xffffu;
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+                if (hit) { const float* px = im + ((size_t)y * g.W + x) * 3; v0 = px[0]; v1 = px[1]; v2 = px[2]; isx += x; }
+                const int n = __popc(m);
+                cnt += n; isy += n * y;
+                while (__any(m != 0u)) {
+                    const int src = sub * UPD_LANES + (m ? __ffs((int)m) - 1 : 0);
+                    const float t0 = __shfl(v0, src, 64), t1 = __shfl(v1, src, 64), t2 = __shfl(v2, src, 64);
+                    if (m) { s0 += t0; s1 += t1; s2 += t2; }
+                    m &= m - 1u;
+                }
             }
         }
+#pragma unroll
+        for (int c = 0; c < UPD_CH; ++c) cur[c] = nxt[c];
+        ry = ry_n; cb = cb_n;
     }
-    if (lane != 0) return;
+#pragma unroll
+    for (int off = 1; off < UPD_LANES; off <<= 1) isx += __shfl_xor(isx, off, 64);
+    float sy = (float)isy, sx = (float)isx;
+    if (live && (isy >= (1 << 24) || isx >= (1 << 24))) {
+        // (never with SLIC-sized clusters) float32 running sums stop being exact: redo them in order
+        sy = 0.f; sx = 0.f;
+        for (int y = bd.x; y < bd.y; ++y)
+            for (int x = bd.z; x < bd.w; ++x)
+                if (lb[(size_t)y * g.W + x] == k) { sy += (float)y; sx += (float)x; }
+    }
+    if (!live || sl != 0) return;
     const float n = (float)cnt;
     const float cy = sy / n, cx = sx / n;
     centers[o * 5 + 0] = cy; centers[o * 5 + 1] = cx;
@@ -682,7 +726,7 @@ extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, co
         }
         {
             ProfScope prof(ctx, st, "slic_update");
-            hipLaunchKernelGGL(k_slic_update, dim3(cdiv(g.K, 4), B), dim3(256), 0, st, g, km_img, raw,
+            hipLaunchKernelGGL(k_slic_update, dim3(cdiv(g.K, 4 * UPD_GROUPS), B), dim3(256), 0, st, g, km_img, raw,
                                stale + (size_t)it * B, centers, bounds);
         }
         GGC_LAUNCH_CHECK(ctx);
