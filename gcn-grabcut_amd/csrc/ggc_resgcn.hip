@@ -564,7 +564,10 @@ __global__ void __launch_bounds__(256) k_agg_pack(int N, const int32_t* __restri
         pk |= (have ? off & 1023 : ZROW) << (10 * nb);
     }
 #pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) regular = regular && __shfl_xor((int)regular, o, LPR);
+    for (int o = 1; o < LPR; o <<= 1) {
+        const int other = __shfl_xor((int)regular, o, LPR);     // every lane takes part: no short-circuit around the shuffle
+        regular = regular && other != 0;
+    }
     if (i < N * LPR) pack[i] = regular ? pk | (n + 1) << 20 : (ZROW | ZROW << 10);
 }
 

@@ -124,3 +124,21 @@ def test_clean_mask_compose_iou_bit_exact(oracle, gpu_ctx):
         o = np.roll(masks, 3, axis=2)[i]
         assert iou[i].item() == pytest.approx(oracle.iou(masks[i], o), abs=1e-12)
         assert cnt[i].tolist() == [int((masks[i] & o).sum()), int((masks[i] & (1 - o)).sum()), int(((1 - masks[i]) & o).sum())]
+
+
+def test_grabcut_lanes_equal_single_stream(gpu_ctx):
+    """The pipeline runs GrabCut as concurrent sub-batches on private contexts / streams (Engine.grabcut_lanes);
+    image b keeps seed + b, so masks and models must equal the single-stream call bit for bit."""
+    from gcn_grabcut._engine import get_engine
+    from gcn_grabcut.synthetic import synthetic_image
+    eng = get_engine("cuda")
+    pairs = [synthetic_image(96, 128, 7100 + i, return_mask=True) for i in range(10)]
+    imgs = np.ascontiguousarray(np.stack([p[0] for p in pairs]))
+    tri = _trimaps(imgs, [p[1] for p in pairs])
+    bgr = torch.from_numpy(imgs).cuda()
+    m1, m2 = torch.from_numpy(tri).cuda(), torch.from_numpy(tri).cuda()
+    b1, m1, bg1, fg1 = eng.grabcut(bgr, m1, 3, 0, None, 5)
+    b2, m2, bg2, fg2 = eng.grabcut_lanes(bgr, m2, 3, 0, 5, 4)
+    torch.cuda.synchronize()
+    assert torch.equal(b1, b2) and torch.equal(m1, m2)
+    assert torch.equal(bg1, bg2) and torch.equal(fg1, fg2)

@@ -74,6 +74,51 @@ def test_isolated_node(oracle, gpu_ctx):
     assert np.isfinite(got).all() and np.abs(got - want).max() <= TOL_LOGITS
 
 
+def _hub_graph(n, hub_deg, seed):
+    """superpixel-like graph plus a hub: node 3 receives hub_deg extra mirrored edges (in-degree > 16)."""
+    x, ei, ea = superpixel_like_graph(n=n, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    have = set(map(tuple, ei.T.tolist()))
+    extra = [j for j in rng.permutation(n) if j != 3 and (int(j), 3) not in have][:hub_deg]
+    src = np.concatenate([ei[0], np.array(extra), np.full(len(extra), 3)])
+    dst = np.concatenate([ei[1], np.full(len(extra), 3), np.array(extra)])
+    ea2 = rng.random((2 * len(extra), 5)).astype(np.float32)
+    return x, np.stack([src, dst]).astype(np.int64), np.concatenate([ea, ea2], 0)
+
+
+@pytest.mark.parametrize("case", ["graph_over_tile", "slice16", "direct", "hub_rows", "edges_leave_graph"])
+def test_forward_aggregation_routes(oracle, gpu_ctx, case):
+    """The forward pass aggregates with the graph-resident LDS kernel; every route around it must give the same
+    logits: a graph larger than the 619-row tile inside a batch of small ones (per-block fallback), a mean size
+    that selects 16-float slices, one that selects the direct gather, rows with more than 16 neighbours, and a
+    batch vector that cuts through edges (neighbours outside the block's graph)."""
+    from gcn_grabcut.data import Batch
+    model, sd = seeded_state_dict(128, 2, seed=3)
+    model = model.to("cuda").eval()
+    if case == "graph_over_tile":
+        graphs = [superpixel_like_graph(n=n, seed=n) for n in (700, 420, 380)]
+    elif case == "slice16":
+        graphs = [superpixel_like_graph(n=n, seed=n) for n in (760, 700)]
+    elif case == "direct":
+        graphs = [superpixel_like_graph(n=1203, seed=5)]
+    elif case == "hub_rows":
+        graphs = [_hub_graph(500, 40, seed=9), superpixel_like_graph(n=300, seed=2)]
+    else:
+        graphs = [superpixel_like_graph(n=600, seed=21)]
+    off = np.cumsum([0] + [g[0].shape[0] for g in graphs])
+    x = np.concatenate([g[0] for g in graphs])
+    ei = np.concatenate([g[1] + off[i] for i, g in enumerate(graphs)], 1)
+    ea = np.concatenate([g[2] for g in graphs])
+    batch = np.concatenate([np.full(g[0].shape[0], i) for i, g in enumerate(graphs)])
+    if case == "edges_leave_graph":
+        batch = (np.arange(600) >= 280).astype(np.int64)          # two "graphs" with edges across the cut
+    want, _ = oracle.resgcn_forward(_np_state(sd), 128, 2, x, ei, ea, batch)
+    d = _data(x, ei, ea, batch=torch.as_tensor(batch))
+    d.num_graphs = int(batch.max()) + 1
+    got = model(d).cpu().numpy()
+    assert np.abs(got - want).max() <= TOL_LOGITS
+
+
 @pytest.mark.parametrize("d", [32, 64, 96, 128])
 def test_aggregate_bit_exact_and_fused(oracle, gpu_ctx, d):
     """M3 alone: CSR build + gather. Unfused output is bit-identical to the oracle

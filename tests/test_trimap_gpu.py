@@ -16,7 +16,8 @@ def _refine(ctx, probs, node_ptr, seg, bgr, thr=0.55, radius=8, eps=1e-3, edge_a
     return tri
 
 
-@pytest.mark.parametrize("h,w,b,n_seg,radius", [(64, 64, 2, 50, 8), (50, 81, 3, 80, 4), (300, 400, 2, 600, 8), (20, 24, 1, 12, 8)])
+@pytest.mark.parametrize("h,w,b,n_seg,radius", [(64, 64, 2, 50, 8), (50, 81, 3, 80, 4), (300, 400, 2, 600, 8), (20, 24, 1, 12, 8),
+                                                  (33, 70, 1, 20, 1), (70, 129, 2, 40, 3), (40, 56, 2, 30, 12)])
 def test_refine_trimap_bit_exact(oracle, gpu_ctx, h, w, b, n_seg, radius):
     from gcn_grabcut.synthetic import synthetic_batch
     bgr_h = synthetic_batch(b, h, w, config_id=6)
