@@ -31,6 +31,7 @@ constexpr int CHUNK = 1024;              // pixels per k-means++ sampling chunk
 struct Gmm {
     double coef[NCOMP], mean[NCOMP][3], cov[NCOMP][9];
     double inv[NCOMP][3][3], det[NCOMP];
+    double isd[NCOMP];                       // 1 / sqrt(det): the per-pixel likelihood multiplies by it (hoisted, same value)
 };
 
 // ------------------------------------------------------------------ GMM math
@@ -43,6 +44,7 @@ __host__ __device__ inline void gmm_prepare(Gmm& g, int ci, double fix) {   // c
         d = c[0] * (c[4] * c[8] - c[5] * c[7]) - c[1] * (c[3] * c[8] - c[5] * c[6]) + c[2] * (c[3] * c[7] - c[4] * c[6]);
     }
     g.det[ci] = d;
+    g.isd[ci] = 1.0 / sqrt(d);
     const double id = 1.0 / d;
     g.inv[ci][0][0] = (c[4] * c[8] - c[5] * c[7]) * id;
     g.inv[ci][1][0] = -(c[3] * c[8] - c[5] * c[6]) * id;
@@ -61,7 +63,7 @@ __device__ __forceinline__ double gmm_comp(const Gmm& g, int ci, const uint8_t* 
     const double mult = d0 * (d0 * g.inv[ci][0][0] + d1 * g.inv[ci][1][0] + d2 * g.inv[ci][2][0])
                       + d1 * (d0 * g.inv[ci][0][1] + d1 * g.inv[ci][1][1] + d2 * g.inv[ci][2][1])
                       + d2 * (d0 * g.inv[ci][0][2] + d1 * g.inv[ci][1][2] + d2 * g.inv[ci][2][2]);
-    return 1.0 / sqrt(g.det[ci]) * det_exp(-0.5 * mult);
+    return g.isd[ci] * det_exp(-0.5 * mult);
 }
 __device__ __forceinline__ double gmm_total(const Gmm& g, const uint8_t* px) {
     double r = 0.0;
@@ -222,35 +224,48 @@ __global__ void k_km_pick(GcDims d, int k, uint64_t seed, const uint8_t* __restr
 // accumulators per (image, class, component): count, 3 sums, 9 products (int64, exact)
 constexpr int ACC_W = 13;
 
+// Block-local bins live in LDS as 32-bit counters.  A wave's 64 pixels fall into a handful of (class, component)
+// bins, so plain LDS atomics would serialise ~13 deep on one address: every bin slot is kept in BIN_COPIES copies in
+// adjacent banks (copy = lane % BIN_COPIES) and summed at the flush.  A block covers BIN_PX pixels per thread, which
+// also divides the number of global 64-bit flush atomics.
+constexpr int BIN_COPIES = 16, BIN_PX = 4;
+
 __global__ void __launch_bounds__(256) k_km_assign(GcDims d, const uint8_t* __restrict__ img,
                                                    const uint8_t* __restrict__ mask, const int32_t* __restrict__ state,
                                                    const KmState* __restrict__ km, uint8_t* __restrict__ comp,
                                                    unsigned long long* __restrict__ acc) {
-    __shared__ unsigned int s_acc[2 * NCOMP * 4];     // 32-bit block-local bins (256 x 255 fits easily)
-    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ unsigned int s_acc[2 * NCOMP * 4 * BIN_COPIES];     // (256 * BIN_PX) x 255 fits 32 bits easily
+    const int b = blockIdx.y, tid = threadIdx.x, cp = tid % BIN_COPIES;
     if (state[b]) return;
-    for (int i = tid; i < 2 * NCOMP * 4; i += 256) s_acc[i] = 0;
+    for (int i = tid; i < 2 * NCOMP * 4 * BIN_COPIES; i += 256) s_acc[i] = 0;
     __syncthreads();
-    const int p = blockIdx.x * 256 + tid;
-    if (p < d.P) {
-        const size_t gp = (size_t)b * d.P + p;
-        const int c = is_bg(mask[gp]) ? 0 : 1;
-        const KmState& s = km[b * 2 + c];
-        const uint8_t* px = img + gp * 3;
-        int best = 0; double bd = 0.0;
-        for (int k = 0; k < s.K; ++k) {
-            const double a0 = (double)px[0] - s.cen[k][0], a1 = (double)px[1] - s.cen[k][1], a2 = (double)px[2] - s.cen[k][2];
-            const double dist = (a0 * a0 + a1 * a1) + a2 * a2;
-            if (k == 0 || dist < bd) { best = k; bd = dist; }
+#pragma unroll
+    for (int j = 0; j < BIN_PX; ++j) {
+        const int p = (blockIdx.x * BIN_PX + j) * 256 + tid;
+        if (p < d.P) {
+            const size_t gp = (size_t)b * d.P + p;
+            const int c = is_bg(mask[gp]) ? 0 : 1;
+            const KmState& s = km[b * 2 + c];
+            const uint8_t* px = img + gp * 3;
+            int best = 0; double bd = 0.0;
+            for (int k = 0; k < s.K; ++k) {
+                const double a0 = (double)px[0] - s.cen[k][0], a1 = (double)px[1] - s.cen[k][1], a2 = (double)px[2] - s.cen[k][2];
+                const double dist = (a0 * a0 + a1 * a1) + a2 * a2;
+                if (k == 0 || dist < bd) { best = k; bd = dist; }
+            }
+            comp[gp] = (uint8_t)best;
+            unsigned int* a = s_acc + (c * NCOMP + best) * 4 * BIN_COPIES + cp;
+            atomicAdd(&a[0], 1u); atomicAdd(&a[BIN_COPIES], (unsigned int)px[0]);
+            atomicAdd(&a[2 * BIN_COPIES], (unsigned int)px[1]); atomicAdd(&a[3 * BIN_COPIES], (unsigned int)px[2]);
         }
-        comp[gp] = (uint8_t)best;
-        unsigned int* a = s_acc + (c * NCOMP + best) * 4;
-        atomicAdd(&a[0], 1u); atomicAdd(&a[1], (unsigned int)px[0]);
-        atomicAdd(&a[2], (unsigned int)px[1]); atomicAdd(&a[3], (unsigned int)px[2]);
     }
     __syncthreads();
-    for (int i = tid; i < 2 * NCOMP * 4; i += 256)
-        if (s_acc[i]) atomicAdd(&acc[((size_t)b * 2 * NCOMP + i / 4) * ACC_W + (i % 4)], (unsigned long long)s_acc[i]);
+    for (int i = tid; i < 2 * NCOMP * 4; i += 256) {
+        unsigned int v = 0;
+#pragma unroll
+        for (int k = 0; k < BIN_COPIES; ++k) v += s_acc[i * BIN_COPIES + k];
+        if (v) atomicAdd(&acc[((size_t)b * 2 * NCOMP + i / 4) * ACC_W + (i % 4)], (unsigned long long)v);
+    }
 }
 
 __global__ void k_km_update(int B, const int32_t* __restrict__ state, KmState* __restrict__ km,
@@ -271,28 +286,32 @@ __global__ void __launch_bounds__(256) k_gmm_accum(GcDims d, const uint8_t* __re
                                                    const uint8_t* __restrict__ mask, const int32_t* __restrict__ state,
                                                    const Gmm* __restrict__ gmm, uint8_t* __restrict__ comp,
                                                    unsigned long long* __restrict__ acc) {
-    // Block-local bins in LDS as 32-bit counters (256 pixels x 255^2 < 2^32), products stored once per
-    // symmetric pair: 10 LDS atomics per pixel; the exact 64-bit totals are formed by the global flush.
+    // Block-local bins in LDS as 32-bit counters (256 * BIN_PX pixels x 255^2 < 2^32), products stored once per
+    // symmetric pair: 10 LDS atomics per pixel into BIN_COPIES-fold privatised slots (see k_km_assign); the exact
+    // 64-bit totals are formed by the global flush.
     constexpr int LW = 10;   // count | 3 sums | xx xy xz yy yz zz
-    __shared__ unsigned int s_acc[2 * NCOMP * LW];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ unsigned int s_acc[2 * NCOMP * LW * BIN_COPIES];
+    const int b = blockIdx.y, tid = threadIdx.x, cp = tid % BIN_COPIES;
     if (state[b]) return;
-    for (int i = tid; i < 2 * NCOMP * LW; i += 256) s_acc[i] = 0;
+    for (int i = tid; i < 2 * NCOMP * LW * BIN_COPIES; i += 256) s_acc[i] = 0;
     __syncthreads();
-    const int p = blockIdx.x * 256 + tid;
-    if (p < d.P) {
-        const size_t gp = (size_t)b * d.P + p;
-        const int c = is_bg(mask[gp]) ? 0 : 1;
-        const uint8_t* px = img + gp * 3;
-        int ci;
-        if (MODE == 1) { ci = gmm_which(gmm[b * 2 + c], px); comp[gp] = (uint8_t)ci; }
-        else ci = comp[gp];
-        unsigned int* a = s_acc + (c * NCOMP + ci) * LW;
-        const unsigned int v0 = px[0], v1 = px[1], v2 = px[2];
-        atomicAdd(&a[0], 1u);
-        atomicAdd(&a[1], v0); atomicAdd(&a[2], v1); atomicAdd(&a[3], v2);
-        atomicAdd(&a[4], v0 * v0); atomicAdd(&a[5], v0 * v1); atomicAdd(&a[6], v0 * v2);
-        atomicAdd(&a[7], v1 * v1); atomicAdd(&a[8], v1 * v2); atomicAdd(&a[9], v2 * v2);
+#pragma unroll
+    for (int j = 0; j < BIN_PX; ++j) {
+        const int p = (blockIdx.x * BIN_PX + j) * 256 + tid;
+        if (p < d.P) {
+            const size_t gp = (size_t)b * d.P + p;
+            const int c = is_bg(mask[gp]) ? 0 : 1;
+            const uint8_t* px = img + gp * 3;
+            int ci;
+            if (MODE == 1) { ci = gmm_which(gmm[b * 2 + c], px); comp[gp] = (uint8_t)ci; }
+            else ci = comp[gp];
+            unsigned int* a = s_acc + (c * NCOMP + ci) * LW * BIN_COPIES + cp;
+            const unsigned int v0 = px[0], v1 = px[1], v2 = px[2];
+            atomicAdd(&a[0], 1u);
+            atomicAdd(&a[1 * BIN_COPIES], v0); atomicAdd(&a[2 * BIN_COPIES], v1); atomicAdd(&a[3 * BIN_COPIES], v2);
+            atomicAdd(&a[4 * BIN_COPIES], v0 * v0); atomicAdd(&a[5 * BIN_COPIES], v0 * v1); atomicAdd(&a[6 * BIN_COPIES], v0 * v2);
+            atomicAdd(&a[7 * BIN_COPIES], v1 * v1); atomicAdd(&a[8 * BIN_COPIES], v1 * v2); atomicAdd(&a[9 * BIN_COPIES], v2 * v2);
+        }
     }
     __syncthreads();
     for (int i = tid; i < 2 * NCOMP * ACC_W; i += 256) {
@@ -303,7 +322,9 @@ __global__ void __launch_bounds__(256) k_gmm_accum(GcDims d, const uint8_t* __re
             const int lo = r < cc ? r : cc, hi = r < cc ? cc : r;
             ls = 4 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5));
         }
-        const unsigned int v = s_acc[bin * LW + ls];
+        unsigned int v = 0;
+#pragma unroll
+        for (int k = 0; k < BIN_COPIES; ++k) v += s_acc[(bin * LW + ls) * BIN_COPIES + k];
         if (v) atomicAdd(&acc[(size_t)b * 2 * NCOMP * ACC_W + i], (unsigned long long)v);
     }
 }
@@ -531,10 +552,10 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
             hipLaunchKernelGGL(k_km_pick, dim3(B), dim3(64), 0, st, d, k, (uint64_t)seed, image, mask, state, d2, chunk_cnt, chunk_d2, km);
         }
         for (int it = 0; it < 10; ++it) {
-            hipLaunchKernelGGL(k_km_assign, dim3(cdiv(d.P, 256), B), dim3(256), 0, st, d, image, mask, state, km, comp, acc);
+            hipLaunchKernelGGL(k_km_assign, dim3(cdiv(d.P, 256 * BIN_PX), B), dim3(256), 0, st, d, image, mask, state, km, comp, acc);
             hipLaunchKernelGGL(k_km_update, dim3(cdiv(B * 2 * NCOMP, 256)), dim3(256), 0, st, B, state, km, acc, it < 9 ? 1 : 0);
         }
-        hipLaunchKernelGGL((k_gmm_accum<0>), dim3(cdiv(d.P, 256), B), dim3(256), 0, st, d, image, mask, state, gmm, comp, acc);
+        hipLaunchKernelGGL((k_gmm_accum<0>), dim3(cdiv(d.P, 256 * BIN_PX), B), dim3(256), 0, st, d, image, mask, state, gmm, comp, acc);
         hipLaunchKernelGGL(k_gmm_learn, dim3(cdiv(B * 2, 64)), dim3(64), 0, st, B, state, acc, gmm);
     }
     GGC_LAUNCH_CHECK(ctx);
@@ -546,7 +567,7 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
         for (int it = 0; it < n_iter; ++it) {
             {
                 ProfScope prof(ctx, st, "grabcut_gmm");
-                hipLaunchKernelGGL((k_gmm_accum<1>), dim3(cdiv(d.P, 256), B), dim3(256), 0, st, d, image, mask, state, gmm, comp, acc);
+                hipLaunchKernelGGL((k_gmm_accum<1>), dim3(cdiv(d.P, 256 * BIN_PX), B), dim3(256), 0, st, d, image, mask, state, gmm, comp, acc);
                 hipLaunchKernelGGL(k_gmm_learn, dim3(cdiv(B * 2, 64)), dim3(64), 0, st, B, state, acc, gmm);
                 static const bool warm_ok = [] { const char* e = std::getenv("GGC_MF_WARM"); return !(e && e[0] == '0'); }();
                 hipLaunchKernelGGL(k_build_graph, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk,
