@@ -28,15 +28,23 @@ __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b) {
     }
 }
 
+// Horizontal runs need no atomics: a pixel's parent starts as the first pixel of its run inside the wave's 64
+// consecutive pixels (ballot of the run breaks); k_cc_merge only joins runs.
 __global__ void __launch_bounds__(256) k_cc_init(PDims d, const uint8_t* __restrict__ mask, int32_t* __restrict__ parent,
                                                  int32_t* __restrict__ total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int on = 0, b = -1;
+    const int lane = threadIdx.x & 63;
+    int on = 0, b = -1, p = 0;
+    bool same_left = false;
     if (i < (size_t)d.B * d.P) {
         on = mask[i] != 0;
         b = (int)(i / d.P);
-        parent[i] = on ? (int)(i % d.P) : -1;
+        p = (int)(i % d.P);
+        same_left = on && (p % d.W) > 0 && mask[i - 1] != 0;
     }
+    const unsigned long long starts = __ballot(on && (!same_left || lane == 0));
+    if (i < (size_t)d.B * d.P)
+        parent[i] = on ? p - (lane - (63 - __clzll((long long)(starts & ((2ull << lane) - 1ull))))) : -1;
     // total[b] != 0  <=>  the image has foreground (pipeline.py:208).  A wave can straddle images.
     if (d.P >= 64) {
         const int b0 = __builtin_amdgcn_readfirstlane(b);
@@ -53,15 +61,26 @@ __global__ void __launch_bounds__(256) k_cc_init(PDims d, const uint8_t* __restr
 __global__ void __launch_bounds__(256) k_cc_merge(PDims d, int32_t* __restrict__ parent) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= d.W || y >= d.H) return;
-    int32_t* par = parent + (size_t)blockIdx.z * d.P;
+    const size_t base = (size_t)blockIdx.z * d.P;
+    int32_t* par = parent + base;
     const int p = y * d.W + x;
     if (par[p] < 0) return;
-    // 8-connectivity: link with the four already-scanned neighbours (left, up-left, up, up-right)
-    if (x > 0 && par[p - 1] >= 0) uf_union(par, p, p - 1);
+    // 8-connectivity with the already-scanned neighbours (left, up-left, up, up-right).  Foreground pixels of one row
+    // that touch are one run already, so a pixel whose left neighbour is foreground only adds what that neighbour
+    // could not see: the up-right pixel when the pixel above is background.
+    const bool left = x > 0 && par[p - 1] >= 0;
+    if (left && ((base + p) & 63) == 0) uf_union(par, p, p - 1);                       // run continues across k_cc_init's wave boundary
     if (y > 0) {
-        if (par[p - d.W] >= 0) uf_union(par, p, p - d.W);
-        if (x > 0 && par[p - d.W - 1] >= 0) uf_union(par, p, p - d.W - 1);
-        if (x + 1 < d.W && par[p - d.W + 1] >= 0) uf_union(par, p, p - d.W + 1);
+        const bool up = par[p - d.W] >= 0;
+        const bool ul = x > 0 && par[p - d.W - 1] >= 0, ur = x + 1 < d.W && par[p - d.W + 1] >= 0;
+        if (left) {
+            if (ur && !up) uf_union(par, p, p - d.W + 1);
+        } else if (up) {
+            uf_union(par, p, p - d.W);
+        } else {
+            if (ul) uf_union(par, p, p - d.W - 1);
+            if (ur) uf_union(par, p, p - d.W + 1);
+        }
     }
 }
 

@@ -404,11 +404,24 @@ __device__ __forceinline__ void cn_union(int32_t* parent, int a, int b) {
 
 struct CnDims { int B, H, W, P, min_size, max_size; };
 
-__global__ void __launch_bounds__(256) k_cn_reset(CnDims d, const uint8_t* __restrict__ pending, int32_t* __restrict__ parent,
-                                                  int32_t* __restrict__ csize) {
+// Horizontal runs need no atomics: inside a wave's 64 consecutive pixels a pixel's parent is set straight to the first
+// pixel of its run (ballot of the run breaks), which is also the run's smallest index.  k_cn_merge then only joins
+// runs: across a 64-pixel boundary, and vertically where a run first touches a run of the row above.
+__global__ void __launch_bounds__(256) k_cn_reset(CnDims d, const int32_t* __restrict__ raw, const uint8_t* __restrict__ pending,
+                                                  int32_t* __restrict__ parent, int32_t* __restrict__ csize) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)d.B * d.P || !pending[i]) return;
-    parent[i] = (int)(i % d.P);
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < (size_t)d.B * d.P && pending[i];
+    bool same_left = false;
+    int p = 0;
+    if (valid) {
+        p = (int)(i % d.P);
+        same_left = (p % d.W) > 0 && pending[i - 1] && raw[i - 1] == raw[i];
+    }
+    const unsigned long long starts = __ballot(valid && (!same_left || lane == 0));
+    if (!valid) return;
+    const int start_lane = 63 - __clzll((long long)(starts & ((2ull << lane) - 1ull)));
+    parent[i] = p - (lane - start_lane);
     csize[i] = 0;
 }
 
@@ -420,8 +433,13 @@ __global__ void __launch_bounds__(256) k_cn_merge(CnDims d, const int32_t* __res
     const int p = y * d.W + x;
     if (!pending[base + p]) return;
     const int l = raw[base + p];
-    if (x > 0 && pending[base + p - 1] && raw[base + p - 1] == l) cn_union(parent + base, p, p - 1);
-    if (y > 0 && pending[base + p - d.W] && raw[base + p - d.W] == l) cn_union(parent + base, p, p - d.W);
+    const bool same_left = x > 0 && pending[base + p - 1] && raw[base + p - 1] == l;
+    if (same_left && ((base + p) & 63) == 0) cn_union(parent + base, p, p - 1);      // run continues across k_cn_reset's wave boundary
+    if (y > 0 && pending[base + p - d.W] && raw[base + p - d.W] == l) {
+        // the left neighbour already joined this pair of runs if it sits under the same upper run
+        const bool joined = same_left && pending[base + p - d.W - 1] && raw[base + p - d.W - 1] == l;
+        if (!joined) cn_union(parent + base, p, p - d.W);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_cn_size(CnDims d, const uint8_t* __restrict__ pending, int32_t* __restrict__ parent,
@@ -633,7 +651,7 @@ static int enforce_connectivity(ggc_ctx* ctx, hipStream_t st, int B, int H, int 
         const dim3 g1(cdiv(BP, 256)), g2(cdiv(W, 64), cdiv(H, 4), B), g64(cdiv(BP, 64));
         for (int round = 0; round < 4096; ++round) {
             GGC_HIP(ctx, hipMemsetAsync(qtop, 0, sizeof(int32_t) * (B + 1), st));
-            hipLaunchKernelGGL(k_cn_reset, g1, dim3(256), 0, st, cd, pending, parent, csize);
+            hipLaunchKernelGGL(k_cn_reset, g1, dim3(256), 0, st, cd, raw, pending, parent, csize);
             hipLaunchKernelGGL(k_cn_merge, g2, dim3(256), 0, st, cd, raw, pending, parent);
             hipLaunchKernelGGL(k_cn_size, g1, dim3(256), 0, st, cd, pending, parent, csize);
             hipLaunchKernelGGL(k_cn_settle, g1, dim3(256), 0, st, cd, pending, parent, csize, n_big);
