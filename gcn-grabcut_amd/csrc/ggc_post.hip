@@ -87,13 +87,26 @@ __global__ void __launch_bounds__(256) k_cc_merge(PDims d, int32_t* __restrict__
 // NB: a wave of a row-block may straddle two images only if P % 64 != 0; total[] is per image so guard by image.
 __global__ void __launch_bounds__(256) k_cc_area(PDims d, int32_t* __restrict__ parent, int32_t* __restrict__ area) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)d.B * d.P) return;
-    const size_t base = (i / d.P) * d.P;
-    const int p = (int)(i - base);
-    if (parent[i] < 0) return;
-    const int r = uf_find(parent + base, p);
-    parent[i] = r;                                          // compress (roots keep pointing at themselves)
-    atomicAdd(&area[base + r], 1);
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < (size_t)d.B * d.P && parent[i] >= 0;
+    bool same_left = false;
+    size_t base = 0;
+    int r = 0;
+    if (valid) {
+        base = (i / d.P) * d.P;
+        const int p = (int)(i - base);
+        same_left = (p % d.W) > 0 && parent[i - 1] >= 0;
+        r = uf_find(parent + base, p);
+        parent[i] = r;                                      // compress (roots keep pointing at themselves)
+    }
+    // one atomic per run (the runs of k_cc_init), not per pixel
+    const unsigned long long vmask = __ballot(valid);
+    const unsigned long long starts = __ballot(valid && (!same_left || lane == 0));
+    if (valid && ((starts >> lane) & 1ull)) {
+        const unsigned long long stop = (starts | ~vmask) >> lane >> 1;
+        const int len = stop ? __ffsll((long long)stop) : 64 - lane;
+        atomicAdd(&area[base + r], len);
+    }
 }
 
 // best[b] = max over components of (area << 32 | ~root): largest area, ties to the first component in raster order

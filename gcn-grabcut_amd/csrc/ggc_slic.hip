@@ -442,14 +442,29 @@ __global__ void __launch_bounds__(256) k_cn_merge(CnDims d, const int32_t* __res
     }
 }
 
-__global__ void __launch_bounds__(256) k_cn_size(CnDims d, const uint8_t* __restrict__ pending, int32_t* __restrict__ parent,
-                                                 int32_t* __restrict__ csize) {
+__global__ void __launch_bounds__(256) k_cn_size(CnDims d, const int32_t* __restrict__ raw, const uint8_t* __restrict__ pending,
+                                                 int32_t* __restrict__ parent, int32_t* __restrict__ csize) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)d.B * d.P || !pending[i]) return;
-    const size_t base = (i / d.P) * d.P;
-    const int r = cn_find(parent + base, (int)(i - base));
-    parent[i] = r;
-    atomicAdd(&csize[base + r], 1);
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < (size_t)d.B * d.P && pending[i];
+    bool same_left = false;
+    size_t base = 0;
+    int r = 0;
+    if (valid) {
+        base = (i / d.P) * d.P;
+        const int p = (int)(i - base);
+        same_left = (p % d.W) > 0 && pending[i - 1] && raw[i - 1] == raw[i];
+        r = cn_find(parent + base, p);
+        parent[i] = r;
+    }
+    // one atomic per run (the runs of k_cn_reset), not per pixel
+    const unsigned long long vmask = __ballot(valid);
+    const unsigned long long starts = __ballot(valid && (!same_left || lane == 0));
+    if (valid && ((starts >> lane) & 1ull)) {
+        const unsigned long long stop = (starts | ~vmask) >> lane >> 1;       // next run start or hole above this lane
+        const int len = stop ? __ffsll((long long)stop) : 64 - lane;
+        atomicAdd(&csize[base + r], len);
+    }
 }
 
 // components below max_size are final; count the ones that still need carving
@@ -653,7 +668,7 @@ static int enforce_connectivity(ggc_ctx* ctx, hipStream_t st, int B, int H, int 
             GGC_HIP(ctx, hipMemsetAsync(qtop, 0, sizeof(int32_t) * (B + 1), st));
             hipLaunchKernelGGL(k_cn_reset, g1, dim3(256), 0, st, cd, raw, pending, parent, csize);
             hipLaunchKernelGGL(k_cn_merge, g2, dim3(256), 0, st, cd, raw, pending, parent);
-            hipLaunchKernelGGL(k_cn_size, g1, dim3(256), 0, st, cd, pending, parent, csize);
+            hipLaunchKernelGGL(k_cn_size, g1, dim3(256), 0, st, cd, raw, pending, parent, csize);
             hipLaunchKernelGGL(k_cn_settle, g1, dim3(256), 0, st, cd, pending, parent, csize, n_big);
             GGC_LAUNCH_CHECK(ctx);
             int32_t h_big = 0;
