@@ -44,26 +44,48 @@ struct RegionStats {
 };
 
 // ---- K1: bounding boxes, frame counts, per-image max gradient
+constexpr int BBOX_ROWS = 32;
 __global__ void __launch_bounds__(256) k_bbox(GDims d, const int32_t* __restrict__ seg, const float* __restrict__ grad,
                                               int4* __restrict__ bbox, int32_t* __restrict__ border,
                                               uint32_t* __restrict__ gmax) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.z;
     float gv = -INFINITY;
-    if (x < d.W && y < d.H) {
-        const size_t p = (size_t)b * d.H * d.W + (size_t)y * d.W + x;
-        const int s = seg[p];
-        // the extremes of a region are always attained on its outline: interior pixels skip the atomics
-        const bool edge = x == 0 || y == 0 || x == d.W - 1 || y == d.H - 1 ||
-                          seg[p - 1] != s || seg[p + 1] != s || seg[p - d.W] != s || seg[p + d.W] != s;
-        if (edge) {
-            int4* bb = bbox + (size_t)b * d.Nmax + s;
-            atomicMin(&bb->x, y); atomicMax(&bb->y, y + 1); atomicMin(&bb->z, x); atomicMax(&bb->w, x + 1);
-        }
+    const int lane = threadIdx.x & 63;
+    // a block walks BBOX_ROWS rows: 4 rows per block made the launch itself (134 k tiny blocks) the cost
+    for (int y = blockIdx.y * BBOX_ROWS + (threadIdx.x >> 6); y < min((int)(blockIdx.y + 1) * BBOX_ROWS, d.H); y += 4) {
+    const bool valid = x < d.W;
+    int s = -1;
+    size_t p = 0;
+    if (valid) {
+        p = (size_t)b * d.H * d.W + (size_t)y * d.W + x;
+        s = seg[p];
         const int mult = (y == 0) + (y == d.H - 1) + (x == 0) + (x == d.W - 1);
         if (mult) atomicAdd(&border[(size_t)b * d.Nmax + s], mult);
-        gv = grad[p];
+        gv = fmaxf(gv, grad[p]);
+    }
+    // A region's pixels inside this wave's 64-pixel row segment form runs; a run's x extremes are its two ends,
+    // so its first lane issues the four min/max atomics for the whole run (4 per run instead of 4 per outline pixel).
+    const int s_left = __shfl_up(s, 1, 64);
+    const unsigned long long vmask = __ballot(valid);
+    const unsigned long long starts = __ballot(valid && (lane == 0 || s_left != s));
+    if (valid && ((starts >> lane) & 1ull)) {
+        const unsigned long long stop = (starts | ~vmask) >> lane >> 1;
+        const int len = stop ? __ffsll((long long)stop) : 64 - lane;
+        int4* bb = bbox + (size_t)b * d.Nmax + s;
+        // ... and a run whose neighbour row holds a same-region run reaching at least as far cannot set that extreme:
+        // only "corner" runs reach the L2 atomic units (their throughput is what bounds this kernel)
+        const int xe = x + len - 1;
+        const bool up = y > 0, dn = y + 1 < d.H;
+        const bool up_s = up && seg[p - d.W] == s, dn_s = dn && seg[p + d.W] == s;
+        const bool up_e = up && seg[p - d.W + len - 1] == s, dn_e = dn && seg[p + d.W + len - 1] == s;
+        if (!up_s && !up_e) atomicMin(&bb->x, y);
+        if (!dn_s && !dn_e) atomicMax(&bb->y, y + 1);
+        const bool left_cov = x > 0 && ((up_s && seg[p - d.W - 1] == s) || (dn_s && seg[p + d.W - 1] == s));
+        const bool right_cov = xe + 1 < d.W && ((up_e && seg[p - d.W + len] == s) || (dn_e && seg[p + d.W + len] == s));
+        if (!left_cov) atomicMin(&bb->z, x);
+        if (!right_cov) atomicMax(&bb->w, xe + 1);
+    }
     }
     for (int o = 32; o > 0; o >>= 1) gv = fmaxf(gv, __shfl_xor(gv, o, 64));
     if ((threadIdx.x & 63) == 0 && gv > -INFINITY) atomicMax(&gmax[b], f2ord_g(gv));
@@ -94,10 +116,19 @@ __global__ void __launch_bounds__(64) k_stats(GDims d, const int32_t* __restrict
     const float gden = (float)((double)ord2f_g(gmax[b]) + 1e-6);
     double cnt = 0, sl[3] = {0, 0, 0}, sl2[3] = {0, 0, 0}, sh[3] = {0, 0, 0};
     double sy = 0, sx = 0, syd = 0, sxd = 0, sb = 0, sg1 = 0, sgn = 0;
+    // The scan is a chain of dependent loads (label -> compare -> next pixel) on a kernel with few waves: read the
+    // labels of 8 pixels ahead in one go so that the chain is paid once per 8 pixels.  Visiting order is unchanged.
+    constexpr int SCAN = 8;
     for (int y = bb.x; y < bb.y; ++y) {
         const size_t row = (size_t)y * W;
-        for (int x = bb.z; x < bb.w; ++x) {
-            if (sg[row + x] != r) continue;
+        for (int x0 = bb.z; x0 < bb.w; x0 += SCAN) {
+          int sv[SCAN];
+#pragma unroll
+          for (int j = 0; j < SCAN; ++j) sv[j] = (x0 + j < bb.w) ? sg[row + x0 + j] : -1;
+#pragma unroll
+          for (int j = 0; j < SCAN; ++j) {
+            if (sv[j] != r) continue;
+            const int x = x0 + j;
             const size_t p = row + x;
             cnt += 1.0;
 #pragma unroll
@@ -121,6 +152,7 @@ __global__ void __launch_bounds__(64) k_stats(GDims d, const int32_t* __restrict
             const float g = gr[p];
             sg1 += (double)g;
             sgn += (double)(g / gden);
+          }
         }
     }
     RegionStats s;
@@ -608,7 +640,7 @@ extern "C" int ggc_graph_count(ggc_ctx* ctx, ggc_stream stream, int B, int H, in
     GGC_HIP(ctx, hipMemsetAsync(small, 0, sizeof(uint32_t) * (size_t)B * 16, st));
     GGC_HIP(ctx, hipMemsetAsync(dense, 0, sizeof(int32_t) * BN * Nmax, st));
     const dim3 pix(cdiv(W, 64), cdiv(H, 4), B);
-    hipLaunchKernelGGL(k_bbox, pix, dim3(256), 0, st, d, segments, grad, bbox, border, gmax);
+    hipLaunchKernelGGL(k_bbox, dim3(cdiv(W, 64), cdiv(H, BBOX_ROWS), B), dim3(256), 0, st, d, segments, grad, bbox, border, gmax);
     {
         ProfScope prof(ctx, st, "graph_stats");
         hipLaunchKernelGGL(k_stats, dim3(cdiv(Nmax, 64), B), dim3(64), 0, st, d, segments, n_nodes, lab, hsv, grad,
