@@ -155,8 +155,14 @@ __global__ void k_init_centers(SlicGeom g, float* __restrict__ centers, int4* __
 
 struct Cand { int k, y0, y1, x0, x1; float cy, cx, c0, c1, c2; };
 
-constexpr int TILE_W = 32, TILE_H = 8;
+constexpr int TILE_W = 32, TILE_H = 16;     // two pixels per thread: (x, y) and (x, y + 8)
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Pixel-centric assignment.  A block owns a 32 x 16 tile; the clusters whose search window touches the tile are
+// compacted (ballot + prefix, ascending k, so the strict '>' keeps skimage's lowest-k tie rule) into LDS once, and
+// every thread scores its TWO pixels against each candidate on the packed-f32 pipe (v_pk_*: same IEEE operations in
+// the same order as the scalar form, two pixels per instruction, one candidate fetch for both).
 __global__ void __launch_bounds__(256) k_slic_assign(SlicGeom g, const float* __restrict__ image,
                                                      const float* __restrict__ centers,
                                                      const int4* __restrict__ bounds,
@@ -166,15 +172,17 @@ __global__ void __launch_bounds__(256) k_slic_assign(SlicGeom g, const float* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
     const int tx0 = blockIdx.x * TILE_W, ty0 = blockIdx.y * TILE_H;
-    const int px = tx0 + (tid & 31), py = ty0 + (tid >> 5);
-    const bool inb = px < g.W && py < g.H;
+    const int px = tx0 + (tid & 31), pya = ty0 + (tid >> 5), pyb = pya + 8;
+    const bool ina = px < g.W && pya < g.H, inb = px < g.W && pyb < g.H;
     const size_t P = (size_t)g.H * g.W;
-    const size_t p = (size_t)b * P + (size_t)py * g.W + px;
-    float i0 = 0.f, i1 = 0.f, i2 = 0.f;
-    if (inb) { i0 = image[3 * p]; i1 = image[3 * p + 1]; i2 = image[3 * p + 2]; }
-    const float fy = (float)py, fx = (float)px;
-    float best = INFINITY;
-    int lab = -1;
+    const size_t pa = (size_t)b * P + (size_t)pya * g.W + px, pb = pa + (size_t)8 * g.W;
+    v2f i0 = 0.f, i1 = 0.f, i2 = 0.f;
+    if (ina) { i0.x = image[3 * pa]; i1.x = image[3 * pa + 1]; i2.x = image[3 * pa + 2]; }
+    if (inb) { i0.y = image[3 * pb]; i1.y = image[3 * pb + 1]; i2.y = image[3 * pb + 2]; }
+    const v2f fy = {(float)pya, (float)pyb};
+    const float fx = (float)px;
+    float best_a = INFINITY, best_b = INFINITY;
+    int lab_a = -1, lab_b = -1;
     const float* cen = centers + (size_t)b * g.K * 5;
     const int4* bnd = bounds + (size_t)b * g.K;
     for (int base = 0; base < g.K; base += 256) {
@@ -200,27 +208,29 @@ __global__ void __launch_bounds__(256) k_slic_assign(SlicGeom g, const float* __
             cand[off + pre] = c;
         }
         __syncthreads();
-        if (inb) {
-            for (int i = 0; i < total; ++i) {
-                const Cand& c = cand[i];
-                if (py >= c.y0 && py < c.y1 && px >= c.x0 && px < c.x1) {
-                    const float ty = c.cy - fy, tx = c.cx - fx;
-                    float d = (ty * ty + tx * tx) * g.sw;
-                    float dc = 0.0f, t;
-                    t = i0 - c.c0; dc += t * t;
-                    t = i1 - c.c1; dc += t * t;
-                    t = i2 - c.c2; dc += t * t;
-                    d += dc;
-                    if (best > d) { best = d; lab = c.k; }
-                }
-            }
+        for (int i = 0; i < total; ++i) {
+            const Cand& c = cand[i];
+            const bool xin = (unsigned)(px - c.x0) < (unsigned)(c.x1 - c.x0);
+            const unsigned hgt = (unsigned)(c.y1 - c.y0);
+            const bool hit_a = xin && (unsigned)(pya - c.y0) < hgt, hit_b = xin && (unsigned)(pyb - c.y0) < hgt;
+            if (!(hit_a || hit_b)) continue;
+            const v2f ty = c.cy - fy;
+            const float tx = c.cx - fx;
+            v2f dd = (ty * ty + tx * tx) * g.sw;
+            v2f t = i0 - c.c0;
+            v2f dc = t * t;                     // (0 + t*t) == t*t exactly
+            t = i1 - c.c1; dc += t * t;
+            t = i2 - c.c2; dc += t * t;
+            dd += dc;
+            if (hit_a && best_a > dd.x) { best_a = dd.x; lab_a = c.k; }
+            if (hit_b && best_b > dd.y) { best_b = dd.y; lab_b = c.k; }
         }
         __syncthreads();
     }
-    if (inb) {
-        if (lab >= 0) labels[p] = lab;
-        else atomicOr(&stale[b], 1);   // no window covers the pixel: it keeps its previous label
-    }
+    bool none = false;
+    if (ina) { if (lab_a >= 0) labels[pa] = lab_a; else none = true; }
+    if (inb) { if (lab_b >= 0) labels[pb] = lab_b; else none = true; }
+    if (none) atomicOr(&stale[b], 1);   // no window covers the pixel: it keeps its previous label
 }
 
 // Centre update.  skimage accumulates float32 running sums over a cluster's pixels in raster order, so the
