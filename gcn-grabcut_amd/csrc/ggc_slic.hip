@@ -235,15 +235,15 @@ __global__ void __launch_bounds__(256) k_slic_assign(SlicGeom g, const float* __
 
 // Centre update.  skimage accumulates float32 running sums over a cluster's pixels in raster order, so the
 // additions of the three colour channels must stay sequential per cluster — but nothing else has to:
-//  * a group of 16 lanes owns a cluster (4 clusters per wave, neighbours along the seed grid, so their windows
-//    and shapes are alike): the group reads a window row as 4 chunks of 16 consecutive labels, all four loads —
-//    and those of the next row — in flight together (the scan is otherwise a chain of L2 round trips), a ballot
-//    marks the cluster's pixels, the matching lanes fetch their colours;
+//  * a group of 8 lanes owns a cluster (8 clusters per wave, neighbours along the seed grid, so their windows
+//    and shapes are alike; 16 and 4 lanes measured slower): the group reads a window row as chunks of 8 consecutive
+//    labels, the loads of a whole row block — and those of the next one — in flight together (the scan is otherwise
+//    a chain of L2 round trips), a ballot marks the cluster's pixels, the matching lanes fetch their colours;
 //  * the coordinate sums are sums of small integers: exact in float32 in any order while they stay below 2^24, so
 //    they are taken as integer popcount / lane-local sums (a cluster that large falls back to the ordered loop);
 //  * the colour fold walks the set bits of each group's ballot in ascending x with one ds_bpermute per channel,
-//    all four groups in the same wave instruction.  Same additions, same order, a quarter of the instructions.
-constexpr int UPD_LANES = 16, UPD_GROUPS = 64 / UPD_LANES, UPD_CH = 4;
+//    all groups in the same wave instruction.  Same additions, same order, a fraction of the instructions.
+constexpr int UPD_LANES = 8, UPD_GROUPS = 64 / UPD_LANES, UPD_CH = 8;
 
 __global__ void __launch_bounds__(256) k_slic_update(SlicGeom g, const float* __restrict__ image,
                                                      const int32_t* __restrict__ labels,
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256) k_slic_update(SlicGeom g, const float* __
             const unsigned long long bal = __ballot(hit);
             if (bal) {
                 const int x = bd.z + (cb * UPD_CH + c) * UPD_LANES + sl;
-                unsigned int m = (unsigned int)(bal >> (sub * UPD_LANES)) & 0xffffu;
+                unsigned int m = (unsigned int)(bal >> (sub * UPD_LANES)) & ((1u << UPD_LANES) - 1u);
                 float v0 = 0.f, v1 = 0.f, v2 = 0.f;
                 if (hit) { const float* px = im + ((size_t)y * g.W + x) * 3; v0 = px[0]; v1 = px[1]; v2 = px[2]; isx += x; }
                 const int n = __popc(m);
