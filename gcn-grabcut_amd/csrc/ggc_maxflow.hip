@@ -329,6 +329,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     const bool trace = std::getenv("GGC_MF_TRACE") != nullptr;
     // schedule measured on MI355X (tools/mf_sweep.sh)
     static const int n_launch = env_int("GGC_MF_PR_LAUNCHES", 24), n_inner = env_int("GGC_MF_PR_INNER", 8);
+    static const int n_launch0 = env_int("GGC_MF_PR_LAUNCHES0", 12);
     static const int tail_active = env_int("GGC_MF_TAIL_ACTIVE", 4000), tail_launch = env_int("GGC_MF_TAIL_LAUNCHES", 64);
     const int max_rounds = 4096;
     auto t_prev = std::chrono::steady_clock::now();
@@ -385,7 +386,8 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
         {
             ProfScope prof(ctx, st, "maxflow_push");
             // few active pixels: their labels stay exact, so more (cheap) launches beat another global relabel
-            const int launches = total_active <= tail_active ? tail_launch : n_launch;
+            // first round: labels go stale fastest while most excess is still moving, an early relabel pays (12 vs 24: +3 %)
+            const int launches = total_active <= tail_active ? tail_launch : (round == 0 ? n_launch0 : n_launch);
             for (int phase = 0; phase < launches; ++phase)
                 hipLaunchKernelGGL(k_mf_pr_list, dim3(pr_grid), dim3(256), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
                                    pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
