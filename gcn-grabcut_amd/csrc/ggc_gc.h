@@ -25,7 +25,4 @@ __device__ __forceinline__ int dir_nb(const GcDims& d, int y, int x, int dir) {
 int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
             int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists, int32_t* flags);
 
-// small synchronous device -> host read (stream sync)
-int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std::vector<int32_t>& host);
-
 } // namespace ggc

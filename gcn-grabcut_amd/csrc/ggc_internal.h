@@ -81,6 +81,8 @@ struct ggc_ctx {
 namespace ggc {
 
 int set_err(ggc_ctx* ctx, int code, const char* fmt, ...);
+// small synchronous device -> host read through the context's pinned staging buffer (stream sync)
+int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std::vector<int32_t>& host);
 // Returns nullptr (and sets error) on failure. Content is NOT preserved on growth.
 void* scratch(ggc_ctx* ctx, int slot, size_t bytes);
 

@@ -252,3 +252,58 @@ extern "C" int ggc_mask_iou(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
 }
+
+// ------------------------------------------------------------------ D0: region label statistics
+namespace ggc {
+// One wave covers 64 consecutive pixels of an image; the pixels of one region inside it form runs, and a run adds its
+// length (and its foreground count) with one atomic each — integer sums, exact in any order.
+__global__ void __launch_bounds__(256) k_region_label_stats(PDims d, const int32_t* __restrict__ seg, const uint8_t* __restrict__ gt,
+                                                            const int32_t* __restrict__ node_ptr, int32_t* __restrict__ counts,
+                                                            int32_t* __restrict__ fg) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int n0 = node_ptr[b], n = node_ptr[b + 1] - n0;
+    for (int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; p0 < d.P; p0 += gridDim.x * 256) {
+        const int p = p0 + lane;
+        int s = -1, on = 0;
+        if (p < d.P) {
+            s = seg[(size_t)b * d.P + p];
+            on = gt[(size_t)b * d.P + p] > 0;
+            if (s < 0 || s >= n) s = -1;
+        }
+        const int s_left = __shfl_up(s, 1, 64);
+        const unsigned long long starts = __ballot(lane == 0 || s_left != s);
+        const unsigned long long fgm = __ballot(on != 0);
+        if (s >= 0 && ((starts >> lane) & 1ull)) {
+            const unsigned long long stop = starts >> lane >> 1;
+            const int len = stop ? __ffsll((long long)stop) : 64 - lane;
+            const unsigned long long run = (len == 64 ? ~0ull : ((1ull << len) - 1ull)) << lane;
+            atomicAdd(&counts[n0 + s], len);
+            const int nf = __popcll(fgm & run);
+            if (nf) atomicAdd(&fg[n0 + s], nf);
+        }
+    }
+}
+} // namespace ggc
+
+extern "C" int ggc_region_label_stats(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, const int32_t* segments,
+                                      const uint8_t* gt_mask, const int32_t* node_ptr, int32_t* counts, int32_t* fg) {
+    using namespace ggc;
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, B >= 1 && H >= 1 && W >= 1 && B <= 65535, GGC_E_SHAPE, "bad shape B=%d H=%d W=%d", B, H, W);
+    GGC_REQUIRE(ctx, segments && gt_mask && node_ptr && counts && fg, GGC_E_INVALID_ARG, "null pointer");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const PDims d{B, H, W, H * W};
+    std::vector<int32_t> total;
+    int rc = read_i32(ctx, st, node_ptr + B, 1, total);
+    if (rc) return rc;
+    GGC_REQUIRE(ctx, total[0] >= 0, GGC_E_INVALID_ARG, "node_ptr[B] = %d", total[0]);
+    if (total[0] > 0) {
+        GGC_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)total[0], st));
+        GGC_HIP(ctx, hipMemsetAsync(fg, 0, sizeof(int32_t) * (size_t)total[0], st));
+    }
+    hipLaunchKernelGGL(k_region_label_stats, dim3(std::min(cdiv(d.P, 256), 256), B), dim3(256), 0, st, d, segments, gt_mask, node_ptr,
+                       counts, fg);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}

@@ -3,8 +3,9 @@ GCN-GrabCut on MI355X — host mirror of the reference package src/gcn_grabcut.
 
 Same public names as the reference (__init__.py:57-81) for the per-image
 segmentation hot path; all arithmetic runs in libggc_hip.so (hand-written
-gfx950 kernels behind the C ABI of include/ggc.h).  Training, datasets and
-plotting are out of scope.
+gfx950 kernels behind the C ABI of include/ggc.h).  `dataset` holds the
+graph-cache writer behind tools/prepare_graphs.py (SURVEY.md section 8(f));
+training, loaders and plotting are out of scope.
 """
 from ._constants import N_NODE_FEATS, N_EDGE_FEATS, N_PRIOR_FEATS, N_IMAGE_FEATS
 from .data import Data, Batch

@@ -51,6 +51,7 @@ SIGNATURES = {
     "ggc_clean_mask": [_vp, _vp, _i, _i, _i, _vp, _f, _i, _vp],
     "ggc_compose_outputs": [_vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp],
     "ggc_mask_iou": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "ggc_region_label_stats": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"ggc_last_error": C.c_char_p}
 

@@ -251,6 +251,15 @@ int ggc_compose_outputs(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
 int ggc_mask_iou(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                  const uint8_t* pred, const uint8_t* gt, double* iou, uint64_t* counts);
 
+/* D0 — per-region ground-truth coverage for the graph-cache writer: the integer sums behind
+ * derive_trimap_labels and prepare_sample's fg_ratio (dataset.py:194-206, 245-248):
+ *   counts[n] = pixels of region n,  fg[n] = pixels of region n with gt_mask > 0.
+ *   segments [dev] i32 [B,H,W] (local labels)   gt_mask [dev] u8 [B,H,W]   node_ptr [dev] i32 [B+1]
+ *   counts, fg [dev] i32 [node_ptr[B]]   (labels outside an image's node range are ignored) */
+int ggc_region_label_stats(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
+                           const int32_t* segments, const uint8_t* gt_mask, const int32_t* node_ptr,
+                           int32_t* counts, int32_t* fg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,74 @@
+"""Host logic of the graph-cache writer: descriptors, cache keys, label derivation."""
+import hashlib
+import zlib
+
+import numpy as np
+import pytest
+
+from gcn_grabcut import dataset as ds
+from gcn_grabcut.graph_builder import SuperpixelGraphConfig
+
+
+def _write(path, arr):
+    from PIL import Image
+    Image.fromarray(arr).save(path)
+
+
+def test_list_pairs_orders_and_seeds(tmp_path):
+    (tmp_path / "im").mkdir(); (tmp_path / "mk").mkdir()
+    rng = np.random.default_rng(0)
+    for name in ("b", "a", "c"):
+        _write(tmp_path / "im" / f"{name}.jpg", rng.integers(0, 255, (8, 9, 3), dtype=np.uint8))
+    _write(tmp_path / "mk" / "a.png", np.zeros((8, 9), np.uint8))
+    _write(tmp_path / "mk" / "c.bmp", np.zeros((8, 9), np.uint8))
+    out = ds.list_image_mask_pairs(tmp_path / "im", tmp_path / "mk", max_size=384, augment_copies=2, seed=42)
+    assert [s["name"] for s in out] == ["a", "a_aug0", "a_aug1", "c", "c_aug0", "c_aug1"]      # b has no mask
+    assert out[0]["aug_seed"] is None and out[0]["max_size"] == 384
+    # reference dataset.py:303-309: seed + 1000003 * k + crc32(stem) % 100003
+    assert out[2]["aug_seed"] == 42 + 1000003 * 1 + zlib.crc32(b"a") % 100003
+    assert out[3]["mask_path"].endswith("c.bmp")
+    with pytest.raises(NotImplementedError):
+        ds.materialise(out[1])
+
+
+def test_cache_key_is_the_reference_recipe():
+    s = {"image_path": "/d/im/x.jpg", "mask_path": "/d/mk/x.png", "max_size": 384, "aug_seed": None}
+    cfg = SuperpixelGraphConfig(n_segments=300)
+    h = hashlib.sha1()
+    h.update(repr(("/d/im/x.jpg", "/d/mk/x.png", 384, None)).encode())
+    h.update(repr((cfg.n_segments, cfg.compactness, cfg.sigma, cfg.use_lab, cfg.connectivity, cfg.n_nonlocal, 0.7, 0.7)).encode())
+    assert ds._cache_key(s, cfg, 0.7, 0.7) == h.hexdigest()[:20]
+    assert ds._cache_key(s, cfg, 0.7, 0.7) != ds._cache_key(s, SuperpixelGraphConfig(n_segments=301), 0.7, 0.7)
+    mem = {"image": np.zeros((4, 4, 3), np.uint8), "gt_mask": np.zeros((4, 4), np.uint8)}
+    assert len(ds._cache_key(mem, None, 0.7, 0.7)) == 20
+
+
+def test_derive_trimap_labels_matches_the_reference_formula():
+    rng = np.random.default_rng(1)
+    seg = rng.integers(0, 40, (60, 70)).astype(np.int32)
+    seg[seg == 7] = 8                                      # an empty region id
+    gt = (rng.random((60, 70)) < 0.5).astype(np.uint8)
+    gt[seg < 10] = 1; gt[(seg >= 10) & (seg < 20)] = 0
+    got = ds.derive_trimap_labels(seg, gt, 0.75, 0.75)
+    n = int(seg.max()) + 1
+    counts = np.bincount(seg.ravel(), minlength=n).astype(np.float64)       # dataset.py:197-205 verbatim arithmetic
+    ratio = np.bincount(seg.ravel(), weights=(gt.ravel() > 0).astype(np.float64), minlength=n) / np.maximum(counts, 1.0)
+    want = np.full(n, 1, np.int64); want[ratio >= 0.75] = 2; want[ratio <= 0.25] = 0; want[counts == 0] = 1
+    assert got.dtype == np.int64 and np.array_equal(got, want)
+    assert got[7] == 1 and (got[:7] == 2).all() and (got[10:20] == 0).all()
+
+
+def test_materialise_decodes_resizes_and_filters(tmp_path):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 255, (100, 160, 3), dtype=np.uint8)
+    mask = np.zeros((100, 160), np.uint8); mask[20:80, 30:120] = 255
+    _write(tmp_path / "i.png", img[:, :, ::-1]); _write(tmp_path / "m.png", mask)          # file holds RGB
+    s = {"image_path": str(tmp_path / "i.png"), "mask_path": str(tmp_path / "m.png"), "max_size": 512, "name": "i", "aug_seed": None}
+    m = ds.materialise(s)
+    assert np.array_equal(m["image"], img) and m["gt_mask"].sum() == 60 * 90 and m["image"].flags.c_contiguous
+    m = ds.materialise({**s, "max_size": 80})
+    assert m["image"].shape == (50, 80, 3) and m["gt_mask"].shape == (50, 80) and set(np.unique(m["gt_mask"])) == {0, 1}
+    assert ds.materialise({**s, "mask_path": str(tmp_path / "nope.png")}) is None
+    _write(tmp_path / "m2.png", np.zeros((100, 160), np.uint8))
+    assert ds.materialise({**s, "mask_path": str(tmp_path / "m2.png")}) is None            # degenerate: no foreground
+    assert ds.materialise({"image": img, "gt_mask": mask}) is not None                       # in-memory samples pass through
