@@ -51,6 +51,27 @@ def test_full_pipeline_matches_oracle_on_duts_shape_batch(oracle, pipe128):
         assert set(np.unique(r.binary_mask)) <= {0, 1} and set(np.unique(r.trimap)) <= {0, 1, 2, 3}
 
 
+@pytest.mark.parametrize("b,h,w,n_seg", [(3, 75, 101, 60), (40, 64, 96, 50), (1, 130, 67, 90)])
+def test_full_pipeline_matches_oracle_on_odd_shapes(oracle, b, h, w, n_seg):
+    """Widths / pixel counts that are not multiples of 64, one image, and a batch large enough for the GrabCut lanes
+    (b >= 32): every tile-edge, run-boundary and lane-split path against the oracle."""
+    from gcn_grabcut import GCNGrabCutPipeline, SuperpixelGraphConfig
+    from gcn_grabcut.synthetic import synthetic_batch
+    model, sd = seeded_state_dict(32, 2, seed=5)
+    pipe = GCNGrabCutPipeline(model.eval(), sp_config=SuperpixelGraphConfig(n_segments=n_seg), device="cuda")
+    imgs = synthetic_batch(b, h, w, config_id=9)
+    out = pipe.segment_batch_device(pipe._eng.to_device(imgs))
+    seg, tri, binm = out["segments"].cpu().numpy(), out["trimap"].cpu().numpy(), out["binary_mask"].cpu().numpy()
+    st = _np_state(sd)
+    check = range(b) if b <= 4 else (0, 9, 10, 19, 20, 29, 30, b - 1)            # lane boundaries of a 40-image batch
+    for i in check:
+        want = oracle.segment(imgs[i], st, 32, 2, n_segments=n_seg, seed=i)
+        assert np.array_equal(seg[i], want["segments"]), i
+        assert (tri[i] == want["trimap"]).mean() >= 0.9995, i
+        if np.array_equal(tri[i], want["trimap"]):
+            assert np.array_equal(binm[i], want["binary_mask"]), i
+
+
 def test_segment_returns_result_like_reference():
     # reference tests/test.py:435-448
     from gcn_grabcut.model import ResGCNNet
