@@ -307,3 +307,73 @@ extern "C" int ggc_region_label_stats(ggc_ctx* ctx, ggc_stream stream, int B, in
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
 }
+
+// ------------------------------------------------------------------ R1: evaluation tallies
+namespace ggc {
+constexpr int EVAL_N = 14;
+
+__device__ __forceinline__ bool eval_boundary(const PDims& d, const uint8_t* __restrict__ m, int y, int x, int width) {
+    if (!m[(size_t)y * d.W + x]) return false;
+    const int y0 = max(y - width, 0), y1 = min(y + width, d.H - 1), x0 = max(x - width, 0), x1 = min(x + width, d.W - 1);
+    for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx)
+            if (!m[(size_t)yy * d.W + xx]) return true;      // a background pixel inside the window erodes this one
+    return false;
+}
+
+__global__ void __launch_bounds__(256) k_eval_counts(PDims d, const uint8_t* __restrict__ pred, const uint8_t* __restrict__ gt,
+                                                     const uint8_t* __restrict__ trimap, int width,
+                                                     unsigned long long* __restrict__ counts) {
+    __shared__ unsigned int s_cnt[EVAL_N];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid < EVAL_N) s_cnt[tid] = 0;
+    __syncthreads();
+    const uint8_t* pb = pred + (size_t)b * d.P;
+    const uint8_t* gb = gt + (size_t)b * d.P;
+    unsigned int c[EVAL_N];
+#pragma unroll
+    for (int i = 0; i < EVAL_N; ++i) c[i] = 0;
+    for (int p = blockIdx.x * 256 + tid; p < d.P; p += gridDim.x * 256) {
+        const int y = p / d.W, x = p - y * d.W;
+        const bool pp = pb[p] != 0, g = gb[p] != 0;
+        c[0] += pp && g; c[1] += pp && !g; c[2] += !pp && g;
+        if (width > 0) {
+            const bool bp = eval_boundary(d, pb, y, x, width), bg = eval_boundary(d, gb, y, x, width);
+            c[3] += bp; c[4] += bg; c[5] += bp && bg;
+        }
+        if (trimap) {
+            const int t = trimap[(size_t)b * d.P + p];
+            const bool pf = t == GGC_FGD, pbg = t == GGC_BGD;
+            c[6] += pf && g; c[7] += pf && !g; c[8] += !pf && g;
+            c[9] += pbg && !g; c[10] += pbg && g; c[11] += !pbg && !g;
+            c[12] += t == GGC_PR_BGD || t == GGC_PR_FGD;
+            c[13] += ((t == GGC_FGD || t == GGC_PR_FGD) ? 1 : 0) == (int)gb[p];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < EVAL_N; ++i) {
+        unsigned int v = c[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((tid & 63) == 0 && v) atomicAdd(&s_cnt[i], v);
+    }
+    __syncthreads();
+    if (tid < EVAL_N && s_cnt[tid]) atomicAdd(&counts[(size_t)b * EVAL_N + tid], (unsigned long long)s_cnt[tid]);
+}
+} // namespace ggc
+
+extern "C" int ggc_eval_counts(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, const uint8_t* pred, const uint8_t* gt,
+                               const uint8_t* trimap, int boundary_width, uint64_t* counts) {
+    using namespace ggc;
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, B >= 1 && H >= 1 && W >= 1 && B <= 65535, GGC_E_SHAPE, "bad shape B=%d H=%d W=%d", B, H, W);
+    GGC_REQUIRE(ctx, pred && gt && counts, GGC_E_INVALID_ARG, "null pointer");
+    GGC_REQUIRE(ctx, boundary_width <= 64, GGC_E_INVALID_ARG, "boundary width %d out of range", boundary_width);
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const PDims d{B, H, W, H * W};
+    GGC_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(uint64_t) * (size_t)B * EVAL_N, st));
+    hipLaunchKernelGGL(k_eval_counts, dim3(std::min(cdiv(d.P, 256), 128), B), dim3(256), 0, st, d, pred, gt, trimap, boundary_width,
+                       reinterpret_cast<unsigned long long*>(counts));
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}

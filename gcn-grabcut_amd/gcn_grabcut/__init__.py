@@ -13,7 +13,7 @@ from .grabcut import GrabCut, GrabCutConfig, Label
 from .graph_builder import (
     GraphBuilder, SuperpixelGraph, SuperpixelGraphConfig, compute_auto_prior, encode_user_hints,
 )
-from .metrics import evaluate, SegmentationMetrics
+from .metrics import evaluate, evaluate_batch, evaluate_trimap, boundary_f1, SegmentationMetrics, TrimapMetrics
 from .model import (
     ResGCNNet, build_model, _probs_to_trimap, probs_to_node_trimap, project_to_pixels,
     TRIMAP_BG, TRIMAP_FG, TRIMAP_PROB_BG, TRIMAP_PROB_FG, CLASS_BG, CLASS_UNK, CLASS_FG,
@@ -27,7 +27,7 @@ __all__ = [
     "GrabCut", "GrabCutConfig", "Label",
     "GraphBuilder", "SuperpixelGraph", "SuperpixelGraphConfig", "compute_auto_prior", "encode_user_hints",
     "N_NODE_FEATS", "N_EDGE_FEATS", "N_PRIOR_FEATS",
-    "evaluate", "SegmentationMetrics",
+    "evaluate", "evaluate_batch", "evaluate_trimap", "boundary_f1", "SegmentationMetrics", "TrimapMetrics",
     "GCNGrabCutPipeline", "SegmentationResult", "clean_mask", "guided_filter", "refine_trimap",
     "ResGCNNet", "build_model", "probs_to_node_trimap", "project_to_pixels",
     "Data", "Batch", "synthetic_image", "synthetic_batch",

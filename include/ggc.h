@@ -251,6 +251,17 @@ int ggc_compose_outputs(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
 int ggc_mask_iou(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                  const uint8_t* pred, const uint8_t* gt, double* iou, uint64_t* counts);
 
+/* R1 — integer tallies behind metrics.evaluate / boundary_f1 / evaluate_trimap (metrics.py:58-129, 152-201), per
+ * image.  counts [dev] u64 [B,14]:
+ *   0 tp 1 fp 2 fn (pred / gt != 0)
+ *   3 |pred boundary| 4 |gt boundary| 5 |both|: boundary = m - erode(m, ones(2*width+1)^2) with cv2.erode's default
+ *     border (pixels outside the image never erode); zeros when boundary_width <= 0
+ *   6 fg_tp 7 fg_fp 8 fg_fn 9 bg_tp 10 bg_fp 11 bg_fn 12 probable pixels 13 pixels where (FG|PR_FG) == gt value;
+ *     zeros when trimap == NULL (trimap values as ggc_grabcut's mask). */
+int ggc_eval_counts(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
+                    const uint8_t* pred, const uint8_t* gt, const uint8_t* trimap, int boundary_width,
+                    uint64_t* counts);
+
 /* D0 — per-region ground-truth coverage for the graph-cache writer: the integer sums behind
  * derive_trimap_labels and prepare_sample's fg_ratio (dataset.py:194-206, 245-248):
  *   counts[n] = pixels of region n,  fg[n] = pixels of region n with gt_mask > 0.

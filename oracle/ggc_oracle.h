@@ -112,6 +112,8 @@ void ggo_clean_mask(int H, int W, const uint8_t* mask, float min_area_ratio, int
 void ggo_compose(int H, int W, const uint8_t* bgr, const uint8_t* binary, float alpha,
                  int tb, int tg, int tr, uint8_t* overlay, uint8_t* rgba);
 double ggo_iou(int n, const uint8_t* pred, const uint8_t* gt);
+/* integer tallies behind metrics.evaluate / boundary_f1 / evaluate_trimap (reference metrics.py:58-201); out[14] */
+void ggo_eval_counts(int h, int w, const uint8_t* pred, const uint8_t* gt, const uint8_t* trimap, int width, int64_t* out);
 
 #ifdef __cplusplus
 }

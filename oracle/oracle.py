@@ -320,6 +320,18 @@ def iou(pred, gt):
     return float(L.ggo_iou(_i(pred.size), _p(pred), _p(gt)))
 
 
+def eval_counts(pred, gt, trimap=None, width=3):
+    """int64[14] tallies behind evaluate / boundary_f1 / evaluate_trimap (see oracle/postproc.c)."""
+    L = lib()
+    pred = np.ascontiguousarray(pred, dtype=np.uint8)
+    gt = np.ascontiguousarray(gt, dtype=np.uint8)
+    tri = None if trimap is None else np.ascontiguousarray(trimap, dtype=np.uint8)
+    out = np.zeros(14, np.int64)
+    h, w = pred.shape
+    L.ggo_eval_counts(_i(h), _i(w), _p(pred), _p(gt), _p(tri), _i(width), _p(out))
+    return out
+
+
 # ---------------------------------------------------------------- the whole path
 
 def segment(bgr, state, hidden, n_layers, n_segments=300, compactness=10.0, sigma=1.0, connectivity=4,

@@ -84,3 +84,47 @@ double ggo_iou(int n, const uint8_t* pred, const uint8_t* gt) {
     }
     return (double)tp / ((double)(tp + fp + fn) + 1e-8);
 }
+
+/* Evaluation counts (reference metrics.py:58-129, 152-201): integer tallies behind evaluate / boundary_f1 /
+ * evaluate_trimap for one image.  out[14]:
+ *   0 tp 1 fp 2 fn                      binary confusion, pred/gt != 0 (:72-75)
+ *   3 |pred boundary| 4 |gt boundary| 5 |both|   boundary = m - erode(m, ones(2w+1)^2), cv2.erode's default border
+ *                                        (pixels outside the image never erode) (:117-125); zeros when width <= 0
+ *   6 fg_tp 7 fg_fp 8 fg_fn 9 bg_tp 10 bg_fp 11 bg_fn 12 probable pixels 13 pixels where (FG|PR_FG) == gt value
+ *                                        (:171-194); zeros when trimap == NULL.  Trimap values: 0 BG, 1 FG, 2 PR_BG, 3 PR_FG. */
+static int ggo_is_boundary(int h, int w, const uint8_t* m, int y, int x, int width) {
+    if (!m[(size_t)y * w + x]) return 0;
+    for (int dy = -width; dy <= width; ++dy)
+        for (int dx = -width; dx <= width; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+            if (!m[(size_t)yy * w + xx]) return 1;
+        }
+    return 0;
+}
+
+void ggo_eval_counts(int h, int w, const uint8_t* pred, const uint8_t* gt, const uint8_t* trimap, int width, int64_t* out) {
+    for (int i = 0; i < 14; ++i) out[i] = 0;
+    uint8_t* pb = (uint8_t*)malloc((size_t)h * w);
+    uint8_t* gb = (uint8_t*)malloc((size_t)h * w);
+    for (size_t i = 0; i < (size_t)h * w; ++i) { pb[i] = pred[i] != 0; gb[i] = gt[i] != 0; }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const size_t i = (size_t)y * w + x;
+            const int p = pb[i], g = gb[i];
+            out[0] += p & g; out[1] += p & (!g); out[2] += (!p) & g;
+            if (width > 0) {
+                const int bp = ggo_is_boundary(h, w, pb, y, x, width), bg = ggo_is_boundary(h, w, gb, y, x, width);
+                out[3] += bp; out[4] += bg; out[5] += bp & bg;
+            }
+            if (trimap) {
+                const int t = trimap[i];
+                const int pf = t == 1, pbg = t == 0, prob = t == 2 || t == 3;
+                out[6] += pf & g; out[7] += pf & (!g); out[8] += (!pf) & g;
+                out[9] += pbg & (!g); out[10] += pbg & g; out[11] += (!pbg) & (!g);
+                out[12] += prob;
+                out[13] += ((t == 1 || t == 3) ? 1 : 0) == gt[i];
+            }
+        }
+    free(pb); free(gb);
+}
