@@ -272,6 +272,7 @@ struct GemmArgs {
     const float* gvec;               // MODE 2: [G,D]
     const float *ep_w, *ep_b;        // MODE 1: LN weight/bias; MODE 2: head weight [3,D] / bias [3]
     float *out, *out2;               // MODE 2: logits / probs (either may be null)
+    int accumulate = 0;              // MODE 3: out += A W^T instead of out = A W^T
 };
 
 template <int D, int MODE>
@@ -340,7 +341,19 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
     }
 
     // C/D layout: col = 32 t + (lane & 31), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    if (MODE == 0) {
+    if (MODE == 3) {                 // plain product (GCNTrimapNet: no prologue norm), optionally accumulated
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int grow = r0 + (r & 3) + 8 * (r >> 2) + 4 * hk;
+            if (grow < N) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    float* o = g.out + (size_t)grow * D + 32 * t + li;
+                    *o = g.accumulate ? *o + acc[t][r] : acc[t][r];
+                }
+            }
+        }
+    } else if (MODE == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int grow = r0 + (r & 3) + 8 * (r >> 2) + 4 * hk;
@@ -836,13 +849,16 @@ __global__ void __launch_bounds__(256) k_graph_ctx(const int32_t* __restrict__ n
 
 // ------------------------------------------------------------- weight handling
 
-static const float* devp(ggc_ctx* ctx, const std::string& k) {
-    auto it = ctx->model.dev.find(k);
-    return it == ctx->model.dev.end() ? nullptr : reinterpret_cast<const float*>(it->second.p);
+static const float* devp(const ResgcnWeights& m, const std::string& k) {
+    auto it = m.dev.find(k);
+    return it == m.dev.end() ? nullptr : reinterpret_cast<const float*>(it->second.p);
 }
+static const float* devp(ggc_ctx* ctx, const std::string& k) { return devp(ctx->model, k); }
 
-static int upload(ggc_ctx* ctx, const std::string& key, const std::vector<float>& v) {
-    Buf& b = ctx->model.dev[key];
+static int upload(ggc_ctx* ctx, ResgcnWeights& m, const std::string& key, const std::vector<float>& v);
+static int upload(ggc_ctx* ctx, const std::string& key, const std::vector<float>& v) { return upload(ctx, ctx->model, key, v); }
+static int upload(ggc_ctx* ctx, ResgcnWeights& m, const std::string& key, const std::vector<float>& v) {
+    Buf& b = m.dev[key];
     const size_t bytes = v.size() * sizeof(float);
     if (b.bytes < bytes) {
         if (b.p) GGC_HIP(ctx, hipFree(b.p));
@@ -964,7 +980,7 @@ static int launch_gemm(ggc_ctx* ctx, hipStream_t st, int N, const GemmArgs& a) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    ProfScope prof(ctx, st, MODE == 0 ? "gcn_gemm" : MODE == 1 ? "sage_gemm" : "head_gemm");
+    ProfScope prof(ctx, st, MODE == 0 ? "gcn_gemm" : MODE == 1 ? "sage_gemm" : MODE == 2 ? "head_gemm" : "plain_gemm");
     hipLaunchKernelGGL((k_gemm<D, MODE>), dim3(cdiv(N, 128)), dim3(256), lds, st, N, a);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
@@ -1238,6 +1254,334 @@ int ggc_gcn_aggregate(ggc_ctx* ctx, ggc_stream stream, int N, int D, const float
         case 128: return launch_aggregate<128, 0>(ctx, st, N, xw, row_ptr, col, dis, bias, gate, h, h_out);
     }
     return set_err(ctx, GGC_E_UNSUPPORTED, "D=%d unsupported (32, 64, 96, 128)", D);
+}
+
+} // extern "C"
+
+// ===================================================================================================
+// GCNTrimapNet (reference model.py:239-316), eval mode.
+//   in_norm -> Linear(19, D) + BatchNorm + ReLU -> n x ResGCNBlock -> head on the concatenated block outputs
+//   ResGCNBlock (:216-232): h' = (relu(bn(GCNConv(h))) + h) * scatter_mean_dst(sigmoid(W2 relu(W1 e + b1) + b2))
+// Reuses the destination CSR, the f32-MFMA product (k_gemm mode 3, no prologue norm) and the GCNConv gather of the
+// ResGCNNet path.  The per-edge gate MLP is two products over the E x D edge matrix: the 5 -> D layer is an
+// element-wise kernel, the D -> D layer is the same MFMA product with E rows, and the scatter-mean is a CSR-ordered
+// sum fused with the block's BatchNorm / ReLU / residual epilogue.  BatchNorm1d(eval) = (x - mean) / sqrt(var + 1e-5)
+// * w + b, like the oracle.
+// ===================================================================================================
+namespace ggc {
+
+struct BnW { const float *w, *b, *rm, *rv; };
+__device__ __forceinline__ float bn_apply(float x, const BnW& p, int k) {
+    return (x - p.rm[k]) / sqrtf(p.rv[k] + 1e-5f) * p.w[k] + p.b[k];
+}
+
+// in_norm + input_proj: one wave per node
+template <int D>
+__global__ void __launch_bounds__(256) k_gn_input(int N, const float* __restrict__ x, BnW bn_in, const float* __restrict__ w_inT,
+                                                  const float* __restrict__ b_in, BnW bn1, float* __restrict__ h) {
+    constexpr int NC = (D + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int node = wave; node < N; node += n_waves) {
+        float xn[IN_CH];
+#pragma unroll
+        for (int k = 0; k < IN_CH; ++k) xn[k] = bn_apply(x[(size_t)node * IN_CH + k], bn_in, k);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < IN_CH; ++k) acc += xn[k] * w_inT[k * D + c];
+                const float v = bn_apply(acc + b_in[c], bn1, c);
+                h[(size_t)node * D + c] = v > 0.0f ? v : 0.0f;
+            }
+        }
+    }
+}
+
+// first layer of the edge gate MLP: G1[e] = relu(W1 edge_attr[e] + b1), E x D
+template <int D>
+__global__ void __launch_bounds__(256) k_gn_edge1(size_t ED, const float* __restrict__ edge_attr, const float* __restrict__ w1T,
+                                                  const float* __restrict__ b1, float* __restrict__ g1) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ED) return;
+    const size_t e = i / D;
+    const int c = (int)(i % D);
+    const float* a = edge_attr + e * EDGE_CH;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < EDGE_CH; ++k) acc += a[k] * w1T[k * D + c];
+    acc += b1[c];
+    g1[i] = acc > 0.0f ? acc : 0.0f;
+}
+
+// block epilogue: gate = mean over the incoming edges (CSR = edge order) of sigmoid(G2[e] + b2);
+// out = (relu(bn(conv)) + h) * gate.  LPR lanes x float4 per row like the gather kernels.
+template <int D>
+__global__ void __launch_bounds__(256) k_gn_block_out(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ eid,
+                                                      const float* __restrict__ g2, const float* __restrict__ b2,
+                                                      const float* __restrict__ conv, BnW bn, const float* __restrict__ h,
+                                                      float* __restrict__ out) {
+    constexpr int LPR = AggCfg<D>::LPR, RPW = AggCfg<D>::RPW, RPB = AggCfg<D>::RPB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int row = blockIdx.x * RPB + wave * RPW + sub;
+    if (row >= N || sl * 4 >= D) return;
+    const int beg = row_ptr[row], end = row_ptr[row + 1];
+    const int c0 = sl * 4;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = beg; j < end; ++j) {
+        const float4 v = reinterpret_cast<const float4*>(g2 + (size_t)eid[j] * D)[sl];
+        gs[0] += sigmoid_f(v.x + b2[c0 + 0]); gs[1] += sigmoid_f(v.y + b2[c0 + 1]);
+        gs[2] += sigmoid_f(v.z + b2[c0 + 2]); gs[3] += sigmoid_f(v.w + b2[c0 + 3]);
+    }
+    const int cnt = end - beg;
+    const float c = (float)(cnt > 1 ? cnt : 1);
+    const float4 cv = reinterpret_cast<const float4*>(conv + (size_t)row * D)[sl];
+    const float4 hv = reinterpret_cast<const float4*>(h + (size_t)row * D)[sl];
+    const float cin[4] = {cv.x, cv.y, cv.z, cv.w}, hin[4] = {hv.x, hv.y, hv.z, hv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = bn_apply(cin[k], bn, c0 + k);
+        v = v > 0.0f ? v : 0.0f;
+        v = v + hin[k];
+        o[k] = v * (gs[k] / c);
+    }
+    reinterpret_cast<float4*>(out + (size_t)row * D)[sl] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// head tail: z = relu(bn(z0 + b0)) -> Linear(D, D/2) + ReLU -> Linear(D/2, 3) (+ softmax); one wave per node
+template <int D>
+__global__ void __launch_bounds__(256) k_gn_head(int N, const float* __restrict__ z0, const float* __restrict__ b0, BnW bn,
+                                                 const float* __restrict__ w4T /*[D][D/2]*/, const float* __restrict__ b4,
+                                                 const float* __restrict__ w6 /*[3][D/2]*/, const float* __restrict__ b6,
+                                                 float* __restrict__ logits, float* __restrict__ probs) {
+    constexpr int DH = D / 2, NC = (D + 63) / 64;
+    __shared__ float s_z[4][D];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int node = wave; node < N; node += n_waves) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) {
+                const float v = bn_apply(z0[(size_t)node * D + c] + b0[c], bn, c);
+                s_z[wv][c] = v > 0.0f ? v : 0.0f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float a = 0.0f;                                    // hidden unit `lane` of the D/2 layer (D/2 <= 64)
+        if (lane < DH) {
+            for (int k = 0; k < D; ++k) a += s_z[wv][k] * w4T[k * DH + lane];
+            a += b4[lane];
+            a = a > 0.0f ? a : 0.0f;
+        }
+        float p[N_CLS];
+#pragma unroll
+        for (int c = 0; c < N_CLS; ++c) {
+            // index-order sum like the oracle: lane k contributes a_k * w6[c][k], folded sequentially by lane 0
+            p[c] = (lane < DH) ? a * w6[c * DH + lane] : 0.0f;
+        }
+        float lg[N_CLS] = {0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < DH; ++k) {
+#pragma unroll
+            for (int c = 0; c < N_CLS; ++c) lg[c] += __shfl(p[c], k, 64);
+        }
+        if (lane == 0) {
+            const float l0 = lg[0] + b6[0], l1 = lg[1] + b6[1], l2 = lg[2] + b6[2];
+            if (logits) { logits[(size_t)node * 3 + 0] = l0; logits[(size_t)node * 3 + 1] = l1; logits[(size_t)node * 3 + 2] = l2; }
+            if (probs) {
+                const float mx = fmaxf(l0, fmaxf(l1, l2));
+                const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
+                const float s = (e0 + e1) + e2;
+                probs[(size_t)node * 3 + 0] = e0 / s; probs[(size_t)node * 3 + 1] = e1 / s; probs[(size_t)node * 3 + 2] = e2 / s;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static const char* const BN_KEYS[4] = {"weight", "bias", "running_mean", "running_var"};
+
+static std::vector<Need> needed_gcnnet(const ResgcnWeights& m) {
+    const int D = m.D, n = m.n_layers;
+    std::vector<Need> v;
+    for (const char* k : BN_KEYS) v.push_back({std::string("in_norm.norm.") + k, IN_CH});
+    v.push_back({"input_proj.0.weight", (int64_t)D * IN_CH}); v.push_back({"input_proj.0.bias", D});
+    for (const char* k : BN_KEYS) v.push_back({std::string("input_proj.1.") + k, D});
+    for (int i = 0; i < n; ++i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        v.push_back({p + "conv.bias", D}); v.push_back({p + "conv.lin.weight", (int64_t)D * D});
+        for (const char* k : BN_KEYS) v.push_back({p + "bn." + k, D});
+        v.push_back({p + "edge_inject.proj.0.weight", (int64_t)D * EDGE_CH}); v.push_back({p + "edge_inject.proj.0.bias", D});
+        v.push_back({p + "edge_inject.proj.2.weight", (int64_t)D * D}); v.push_back({p + "edge_inject.proj.2.bias", D});
+    }
+    v.push_back({"head.0.weight", (int64_t)D * D * (n + 1)}); v.push_back({"head.0.bias", D});
+    for (const char* k : BN_KEYS) v.push_back({std::string("head.1.") + k, D});
+    v.push_back({"head.4.weight", (int64_t)(D / 2) * D}); v.push_back({"head.4.bias", D / 2});
+    v.push_back({"head.6.weight", (int64_t)N_CLS * (D / 2)}); v.push_back({"head.6.bias", N_CLS});
+    return v;
+}
+
+static int check_ready_gcnnet(ggc_ctx* ctx) {
+    ResgcnWeights& m = ctx->model2;
+    GGC_REQUIRE(ctx, m.D > 0, GGC_E_STATE, "ggc_gcnnet_configure has not been called");
+    for (const Need& nd : needed_gcnnet(m)) {
+        auto it = m.host.find(nd.key);
+        GGC_REQUIRE(ctx, it != m.host.end(), GGC_E_STATE, "missing weight '%s'", nd.key.c_str());
+        GGC_REQUIRE(ctx, (int64_t)it->second.size() == nd.numel, GGC_E_SHAPE, "weight '%s' has %zu elements, expected %lld",
+                    nd.key.c_str(), it->second.size(), (long long)nd.numel);
+    }
+    return GGC_OK;
+}
+
+static int prepare_weights_gcnnet(ggc_ctx* ctx) {
+    ResgcnWeights& m = ctx->model2;
+    if (m.dev_ok) return GGC_OK;
+    int rc = check_ready_gcnnet(ctx);
+    if (rc) return rc;
+    const int D = m.D, n = m.n_layers;
+    for (auto& kv : m.host) { if ((rc = upload(ctx, m, kv.first, kv.second))) return rc; }
+    if ((rc = upload(ctx, m, "#input_proj.0.weightT", transpose(m.host["input_proj.0.weight"], D, IN_CH)))) return rc;
+    if ((rc = upload(ctx, m, "#head.4.weightT", transpose(m.host["head.4.weight"], D / 2, D)))) return rc;
+    for (int i = 0; i < n; ++i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        if ((rc = upload(ctx, m, "#" + p + "conv.lin.weight.p", pack_mfma(m.host[p + "conv.lin.weight"], D)))) return rc;
+        if ((rc = upload(ctx, m, "#" + p + "edge_inject.proj.0.weightT", transpose(m.host[p + "edge_inject.proj.0.weight"], D, EDGE_CH)))) return rc;
+        if ((rc = upload(ctx, m, "#" + p + "edge_inject.proj.2.weight.p", pack_mfma(m.host[p + "edge_inject.proj.2.weight"], D)))) return rc;
+    }
+    const std::vector<float>& hw = m.host["head.0.weight"];       // [D][D (n+1)]: one D x D block per concatenated state
+    for (int s = 0; s <= n; ++s) {
+        std::vector<float> blk((size_t)D * D);
+        for (int o = 0; o < D; ++o)
+            for (int k = 0; k < D; ++k) blk[(size_t)o * D + k] = hw[(size_t)o * D * (n + 1) + (size_t)s * D + k];
+        if ((rc = upload(ctx, m, "#head.0.weight.p" + std::to_string(s), pack_mfma(blk, D)))) return rc;
+    }
+    m.dev_ok = true;
+    return GGC_OK;
+}
+
+static BnW bn_of(const ResgcnWeights& m, const std::string& prefix) {
+    return BnW{devp(m, prefix + "weight"), devp(m, prefix + "bias"), devp(m, prefix + "running_mean"), devp(m, prefix + "running_var")};
+}
+
+template <int D>
+static int forward_gcnnet_t(ggc_ctx* ctx, hipStream_t st, int N, int E, const float* x, const int32_t* edge_src,
+                            const int32_t* edge_dst, const float* edge_attr, float* logits, float* probs) {
+    ResgcnWeights& m = ctx->model2;
+    const int n = m.n_layers, n_states = n + 1;
+    const size_t ND = (size_t)N * D, ED = (size_t)std::max(E, 1) * D;
+    int32_t* row_ptr = scratch_t<int32_t>(ctx, S_CSR_ROWPTR, (size_t)N + 1);
+    int32_t* col = scratch_t<int32_t>(ctx, S_CSR_COL, (size_t)std::max(E, 1));
+    int32_t* eid = scratch_t<int32_t>(ctx, S_CSR_EID, (size_t)std::max(E, 1));
+    int32_t* cursor = scratch_t<int32_t>(ctx, S_CSR_CURSOR, (size_t)N + 1);
+    float* dis = scratch_t<float>(ctx, S_DIS, (size_t)N);
+    float* states = scratch_t<float>(ctx, S_STATES, ND * n_states);
+    float* xw = scratch_t<float>(ctx, S_XW, ND);
+    float* conv = scratch_t<float>(ctx, S_AGG, ND);
+    float* z0 = scratch_t<float>(ctx, S_HJK, ND);
+    float* g1 = scratch_t<float>(ctx, S_EDGE_A, ED);
+    float* g2 = scratch_t<float>(ctx, S_EDGE_B, ED);
+    if (!row_ptr || !col || !eid || !cursor || !dis || !states || !xw || !conv || !z0 || !g1 || !g2) return GGC_E_OOM;
+    int rc = build_csr(ctx, st, N, E, edge_src, edge_dst, row_ptr, col, eid, cursor, dis);
+    if (rc) return rc;
+    const int wave_blocks = min(cdiv(N, 4), 8 * ctx->n_cu);
+    hipLaunchKernelGGL((k_gn_input<D>), dim3(wave_blocks), dim3(256), 0, st, N, x, bn_of(m, "in_norm.norm."),
+                       devp(m, "#input_proj.0.weightT"), devp(m, "input_proj.0.bias"), bn_of(m, "input_proj.1."), states);
+    GGC_LAUNCH_CHECK(ctx);
+    for (int l = 0; l < n; ++l) {
+        const std::string p = "blocks." + std::to_string(l) + ".";
+        const float* h = states + ND * l;
+        float* out = states + ND * (l + 1);
+        GemmArgs a{};
+        a.A1 = h; a.Wp1 = devp(m, "#" + p + "conv.lin.weight.p"); a.out = xw;
+        if ((rc = launch_gemm<D, 3>(ctx, st, N, a))) return rc;
+        if ((rc = launch_aggregate<D, 0>(ctx, st, N, xw, row_ptr, col, dis, devp(m, p + "conv.bias"), nullptr, nullptr, conv))) return rc;
+        if (E > 0) {
+            hipLaunchKernelGGL((k_gn_edge1<D>), dim3(cdiv((size_t)E * D, 256)), dim3(256), 0, st, (size_t)E * D, edge_attr,
+                               devp(m, "#" + p + "edge_inject.proj.0.weightT"), devp(m, p + "edge_inject.proj.0.bias"), g1);
+            GGC_LAUNCH_CHECK(ctx);
+            GemmArgs e{};
+            e.A1 = g1; e.Wp1 = devp(m, "#" + p + "edge_inject.proj.2.weight.p"); e.out = g2;
+            if ((rc = launch_gemm<D, 3>(ctx, st, E, e))) return rc;
+        }
+        hipLaunchKernelGGL((k_gn_block_out<D>), dim3(cdiv(N, AggCfg<D>::RPB)), dim3(256), 0, st, N, row_ptr, eid, g2,
+                           devp(m, p + "edge_inject.proj.2.bias"), conv, bn_of(m, p + "bn."), h, out);
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    for (int s = 0; s < n_states; ++s) {                       // head.0 on the concatenation = sum of per-state products
+        GemmArgs a{};
+        a.A1 = states + ND * s; a.Wp1 = devp(m, "#head.0.weight.p" + std::to_string(s)); a.out = z0; a.accumulate = s > 0;
+        if ((rc = launch_gemm<D, 3>(ctx, st, N, a))) return rc;
+    }
+    hipLaunchKernelGGL((k_gn_head<D>), dim3(wave_blocks), dim3(256), 0, st, N, z0, devp(m, "head.0.bias"), bn_of(m, "head.1."),
+                       devp(m, "#head.4.weightT"), devp(m, "head.4.bias"), devp(m, "head.6.weight"), devp(m, "head.6.bias"),
+                       logits, probs);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
+
+} // namespace ggc
+
+extern "C" {
+
+int ggc_gcnnet_configure(ggc_ctx* ctx, int hidden, int n_layers) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, hidden == 32 || hidden == 64 || hidden == 96 || hidden == 128, GGC_E_UNSUPPORTED,
+                "hidden_channels=%d unsupported: the MFMA tiling needs a multiple of 32 up to 128", hidden);
+    GGC_REQUIRE(ctx, n_layers >= 1 && n_layers <= 30, GGC_E_INVALID_ARG, "n_layers=%d out of range [1,30]", n_layers);
+    ResgcnWeights& m = ctx->model2;
+    if (m.D != hidden || m.n_layers != n_layers) m.host.clear();
+    m.D = hidden; m.n_layers = n_layers; m.dev_ok = false;
+    return GGC_OK;
+}
+
+int ggc_gcnnet_load_weight(ggc_ctx* ctx, const char* name, const float* data, int64_t numel) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, name && (data || numel == 0) && numel >= 0, GGC_E_INVALID_ARG, "bad weight arguments");
+    GGC_REQUIRE(ctx, ctx->model2.D > 0, GGC_E_STATE, "ggc_gcnnet_configure has not been called");
+    const std::string key(name), tail = "num_batches_tracked";
+    if (key.size() >= tail.size() && key.compare(key.size() - tail.size(), tail.size(), tail) == 0) return GGC_OK;
+    bool known = false;
+    for (const Need& nd : needed_gcnnet(ctx->model2))
+        if (nd.key == key) {
+            GGC_REQUIRE(ctx, nd.numel == numel, GGC_E_SHAPE, "weight '%s' has %lld elements, expected %lld", name,
+                        (long long)numel, (long long)nd.numel);
+            known = true;
+            break;
+        }
+    GGC_REQUIRE(ctx, known, GGC_E_INVALID_ARG, "unexpected state_dict key '%s' for GCNTrimapNet(D=%d, n=%d)", name,
+                ctx->model2.D, ctx->model2.n_layers);
+    ctx->model2.host[key].assign(data, data + numel);
+    ctx->model2.dev_ok = false;
+    return GGC_OK;
+}
+
+int ggc_gcnnet_ready(ggc_ctx* ctx) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    return check_ready_gcnnet(ctx);
+}
+
+int ggc_gcnnet_forward(ggc_ctx* ctx, ggc_stream stream, int N, int E, const float* x, const int32_t* edge_src,
+                       const int32_t* edge_dst, const float* edge_attr, float* logits, float* probs) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, N >= 1 && E >= 0, GGC_E_SHAPE, "bad sizes N=%d E=%d", N, E);
+    GGC_REQUIRE(ctx, x && (E == 0 || (edge_src && edge_dst && edge_attr)), GGC_E_INVALID_ARG, "null input pointer");
+    GGC_REQUIRE(ctx, logits || probs, GGC_E_INVALID_ARG, "both outputs are NULL");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = prepare_weights_gcnnet(ctx);
+    if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (ctx->model2.D) {
+        case 32:  return forward_gcnnet_t<32>(ctx, st, N, E, x, edge_src, edge_dst, edge_attr, logits, probs);
+        case 64:  return forward_gcnnet_t<64>(ctx, st, N, E, x, edge_src, edge_dst, edge_attr, logits, probs);
+        case 96:  return forward_gcnnet_t<96>(ctx, st, N, E, x, edge_src, edge_dst, edge_attr, logits, probs);
+        case 128: return forward_gcnnet_t<128>(ctx, st, N, E, x, edge_src, edge_dst, edge_attr, logits, probs);
+    }
+    return set_err(ctx, GGC_E_STATE, "model not configured");
 }
 
 } // extern "C"

@@ -246,6 +246,112 @@ if _TORCH:
                                       list(self.head.parameters())), "lr": base_lr})
             return groups
 
+    class _EdgeInjection(nn.Module):
+        """Parameter holder for reference EdgeInjectionLayer (model.py:142-162)."""
+        def __init__(self, edge_dim: int, hidden_dim: int):
+            super().__init__()
+            self.proj = nn.Sequential(nn.Linear(edge_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, hidden_dim), nn.Sigmoid())
+
+    class _ResGCNBlock(nn.Module):
+        """Parameter holder for reference ResGCNBlock with in_dim == out_dim (model.py:216-232): `skip` is the identity."""
+        def __init__(self, dim: int, edge_dim: int):
+            super().__init__()
+            self.conv = _GCNConvParams(dim)
+            self.bn = nn.BatchNorm1d(dim)
+            self.edge_inject = _EdgeInjection(edge_dim, dim)
+
+    class GCNTrimapNet(nn.Module):
+        """
+        Baseline GCN with residual blocks, per-block edge injection and a dense-concat head (reference
+        model.py:239-316).  Same `state_dict` keys as the reference module, so a
+        reference checkpoint loads with `load_state_dict`.  Inference only: the forward pass runs in libggc_hip.so
+        (`ggc_gcnnet_forward`) on an MI355X — there is no CPU fallback.
+        """
+
+        def __init__(self, in_channels: int = N_NODE_FEATS, edge_channels: int = N_EDGE_FEATS, hidden_channels: int = 128,
+                     n_layers: int = 6, n_classes: int = 3, dropout: float = 0.2):
+            super().__init__()
+            if in_channels != N_NODE_FEATS or edge_channels != N_EDGE_FEATS or n_classes != 3:
+                raise ValueError("the MI355X kernels are built for 19 node features, 5 edge features and 3 classes")
+            if hidden_channels not in (32, 64, 96, 128):
+                raise ValueError("hidden_channels must be one of 32, 64, 96, 128 (template instantiations of the HIP kernels)")
+            self.n_classes, self.hidden_channels, self.n_layers = n_classes, hidden_channels, n_layers
+            self.in_norm = _InputNorm(in_channels)
+            self.input_proj = nn.Sequential(nn.Linear(in_channels, hidden_channels), nn.BatchNorm1d(hidden_channels), nn.ReLU())
+            self.blocks = nn.ModuleList([_ResGCNBlock(hidden_channels, edge_channels) for _ in range(n_layers)])
+            self.head = nn.Sequential(
+                nn.Linear(hidden_channels * (n_layers + 1), hidden_channels), nn.BatchNorm1d(hidden_channels), nn.ReLU(),
+                nn.Dropout(dropout), nn.Linear(hidden_channels, hidden_channels // 2), nn.ReLU(),
+                nn.Linear(hidden_channels // 2, n_classes))
+            self._uploaded: dict = {}
+
+        def _device_index(self) -> int:
+            dev = self.head[0].weight.device
+            if dev.type != "cuda":
+                raise RuntimeError("GCNTrimapNet runs on an MI355X through libggc_hip.so only; "
+                                   f"the model is on '{dev}'. Move it with .to('cuda') — there is no CPU fallback.")
+            return dev.index if dev.index is not None else torch.cuda.current_device()
+
+        def _sync_weights(self, ctx: "_native.Context") -> None:
+            sd = self.state_dict()
+            fp = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+            if self._uploaded.get(id(ctx)) == fp:
+                return
+            ctx.call("ggc_gcnnet_configure", self.hidden_channels, self.n_layers)
+            for k, v in sd.items():
+                if not v.dtype.is_floating_point:
+                    continue   # num_batches_tracked
+                a = v.detach().to(device="cpu", dtype=torch.float32).contiguous().numpy()
+                ctx.call("ggc_gcnnet_load_weight", k.encode(), a.ctypes.data, a.size)
+            ctx.call("ggc_gcnnet_ready")
+            self._uploaded[id(ctx)] = fp
+
+        def _run(self, data, want_logits: bool, want_probs: bool):
+            if self.training:
+                raise RuntimeError("GCNTrimapNet on MI355X is inference-only: call .eval() first")
+            dev_index = self._device_index()
+            ctx = _native.get_context(dev_index)
+            self._sync_weights(ctx)
+            dev = torch.device("cuda", dev_index)
+            x = data.x
+            if x.device != dev:
+                raise RuntimeError(f"data.x is on {x.device}, model on {dev}")
+            x = x.to(torch.float32).contiguous()
+            n = x.size(0)
+            if x.dim() != 2 or x.size(1) != N_NODE_FEATS:
+                raise ValueError(f"data.x must be (N, {N_NODE_FEATS}), got {tuple(x.shape)}")
+            ei = data.edge_index
+            e = ei.size(1)
+            edge_attr = getattr(data, "edge_attr", None)
+            if edge_attr is None:                      # reference model.py:294-295
+                edge_attr = torch.zeros(e, N_EDGE_FEATS, device=dev)
+            edge_attr = edge_attr.to(torch.float32).contiguous()
+            src, dst = ei[0].to(torch.int32).contiguous(), ei[1].to(torch.int32).contiguous()
+            logits = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_logits else None
+            probs = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_probs else None
+            ctx.call("ggc_gcnnet_forward", _native.current_stream(dev_index), n, e, x.data_ptr(), src.data_ptr(), dst.data_ptr(),
+                     edge_attr.data_ptr(), _native.ptr(logits), _native.ptr(probs))
+            return logits, probs
+
+        def forward(self, data) -> "torch.Tensor":
+            """logits (N, 3) on the model's device — reference model.py:292-304."""
+            with torch.no_grad():
+                return self._run(data, True, False)[0]
+
+        @torch.no_grad()
+        def predict_probs(self, data) -> np.ndarray:
+            self.eval()
+            return self._run(data, False, True)[1].float().cpu().numpy()
+
+        @torch.no_grad()
+        def predict_probs_device(self, data) -> "torch.Tensor":
+            self.eval()
+            return self._run(data, False, True)[1]
+
+        @torch.no_grad()
+        def predict_trimap(self, data, segments: np.ndarray, threshold_fg: float = 0.55, threshold_bg: float = 0.55) -> np.ndarray:
+            return _probs_to_trimap(self.predict_probs(data), segments, threshold_fg, threshold_bg)
+
     def build_model(
         variant: str = "resgcn",
         in_channels: int = N_NODE_FEATS,
@@ -255,14 +361,17 @@ if _TORCH:
         n_classes: int = 3,
         dropout: float = 0.2,
     ) -> "nn.Module":
-        """Factory by name (reference model.py:593-620). Only "resgcn" is on the MI355X hot path."""
+        """Factory by name (reference model.py:593-620): "resgcn" (hot path) and "gcn" run on the MI355X."""
         if variant == "resgcn":
             return ResGCNNet(in_channels=in_channels, edge_channels=edge_channels,
                              hidden_channels=hidden_channels, n_layers=n_layers,
                              n_classes=n_classes, dropout=dropout)
-        if variant in ("gat", "gcn"):
+        if variant == "gcn":
+            return GCNTrimapNet(in_channels=in_channels, edge_channels=edge_channels, hidden_channels=hidden_channels,
+                                n_layers=n_layers, n_classes=n_classes, dropout=dropout)
+        if variant == "gat":
             raise NotImplementedError(
-                f"variant '{variant}' is not part of the MI355X hot path (SURVEY section 8(f)); use 'resgcn'")
+                "variant 'gat' (GATv2 attention) is not built for the MI355X (SURVEY section 8(f), last rank); use 'resgcn' or 'gcn'")
         raise ValueError(f"Unknown variant '{variant}'. Choose: resgcn | gcn | gat")
 
 

@@ -169,6 +169,20 @@ int ggc_resgcn_forward(ggc_ctx* ctx, ggc_stream stream, int G, int N, int E,
                        const float* edge_attr, const int32_t* node_ptr,
                        float* logits, float* probs);
 
+/* GCNTrimapNet, the reference's baseline model (`--model gcn`, model.py:239-316), eval mode.
+ * Same protocol as the ResGCNNet entries: configure, load every float tensor of the state_dict by its key
+ * ("in_norm.norm.weight", "blocks.0.conv.lin.weight", "blocks.0.edge_inject.proj.2.bias", "head.6.weight", ...;
+ * *.num_batches_tracked is ignored), then forward.  The reference's forward takes no batch vector (the model has no
+ * per-graph readout), so a batch is simply the concatenated graphs.
+ *   x [dev] f32 [N,19]  edge_src, edge_dst [dev] i32 [E]  edge_attr [dev] f32 [E,5]
+ *   logits, probs [dev] f32 [N,3] (either may be NULL) */
+int ggc_gcnnet_configure(ggc_ctx* ctx, int hidden_channels, int n_layers);
+int ggc_gcnnet_load_weight(ggc_ctx* ctx, const char* name, const float* data /*[host]*/, int64_t numel);
+int ggc_gcnnet_ready(ggc_ctx* ctx);
+int ggc_gcnnet_forward(ggc_ctx* ctx, ggc_stream stream, int N, int E,
+                       const float* x, const int32_t* edge_src, const int32_t* edge_dst,
+                       const float* edge_attr, float* logits, float* probs);
+
 /* M3 alone — the GCNConv scatter-gather the north star grades (PyG GCNConv
  * inside model.py:523-528).  CSR over destinations, self loops implicit.
  *   out_i = sum_{e: dst(e)=i} dis[src]*dis[i]*xw[src] + dis[i]*dis[i]*xw[i] + bias

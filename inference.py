@@ -65,13 +65,14 @@ def main() -> None:
     import torch
     from src.gcn_grabcut import GCNGrabCutPipeline
     from src.gcn_grabcut.graph_builder import SuperpixelGraphConfig
-    from src.gcn_grabcut.model import ResGCNNet
+    from src.gcn_grabcut.model import GCNTrimapNet, ResGCNNet
     from src.gcn_grabcut.pipeline import _colour_trimap, _write_png
 
     if not torch.cuda.is_available():
         raise SystemExit("[inference] no MI355X visible: this build has no CPU path")
-    if args.model != "resgcn":
-        raise SystemExit(f"[inference] --model {args.model} is not part of the MI355X hot path; use resgcn")
+    if args.model == "gat":
+        raise SystemExit("[inference] --model gat (GATv2 attention) is not built for the MI355X; use resgcn or gcn")
+    model_cls = {"resgcn": ResGCNNet, "gcn": GCNTrimapNet}[args.model]
 
     ckpt_path = Path(args.checkpoint)
     if not ckpt_path.exists():
@@ -83,11 +84,12 @@ def main() -> None:
     state = torch.load(ckpt_path, map_location="cpu", weights_only=True)["model"]
     # width and depth are recovered from the checkpoint (reference inference.py:81-86)
     hidden = state["input_proj.0.weight"].shape[0] if "input_proj.0.weight" in state else args.hidden
-    layers = sum(1 for k in state if k.startswith("gcn_layers.") and k.endswith(".bias")) or args.layers
-    model = ResGCNNet(hidden_channels=hidden, n_layers=layers)
+    layers = (sum(1 for k in state if k.startswith("gcn_layers.") and k.endswith(".bias"))
+              or sum(1 for k in state if k.startswith("blocks.") and k.endswith(".conv.bias")) or args.layers)
+    model = model_cls(hidden_channels=hidden, n_layers=layers)
     model.load_state_dict(state)
     model.eval()
-    print(f"[inference] loaded ResGCNNet (D={hidden}, n={layers}) from {ckpt_path} on {args.device}")
+    print(f"[inference] loaded {model_cls.__name__} (D={hidden}, n={layers}) from {ckpt_path} on {args.device}")
 
     pipeline = GCNGrabCutPipeline(model, sp_config=SuperpixelGraphConfig(n_segments=args.superpixels), device=args.device)
 

@@ -75,6 +75,10 @@ void ggo_auto_prior(int H, int W, const int32_t* segments, const float* lab, int
 
 /* ---- M0-M7: ResGCNNet.forward (model.py:508-536), eval mode ---- */
 int ggo_resgcn_n_params(int n_layers);
+/* GCNTrimapNet.forward, eval mode (reference model.py:239-316); parameter order in oracle/gcnnet.c */
+int ggo_gcnnet_n_params(int n_layers);
+int ggo_gcnnet_forward(const float* const* params, int D, int n_layers, int N, int E, const float* x,
+                       const int64_t* edge_index, const float* edge_attr, float* logits, float* probs);
 int ggo_resgcn_forward(const float* const* params, int D, int n_layers,
                        int N, int E, const float* x, const int64_t* edge_index,
                        const float* edge_attr, const int64_t* batch, int n_graphs,

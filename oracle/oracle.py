@@ -84,6 +84,37 @@ def resgcn_forward(state: dict, hidden: int, n_layers: int, x, edge_index, edge_
     return logits, probs
 
 
+def gcnnet_param_order(n_layers: int) -> list[str]:
+    """GCNTrimapNet state_dict keys in the order oracle/gcnnet.c expects."""
+    bn = ("weight", "bias", "running_mean", "running_var")
+    keys = [f"in_norm.norm.{k}" for k in bn] + ["input_proj.0.weight", "input_proj.0.bias"] + [f"input_proj.1.{k}" for k in bn]
+    for i in range(n_layers):
+        keys += [f"blocks.{i}.conv.bias", f"blocks.{i}.conv.lin.weight"] + [f"blocks.{i}.bn.{k}" for k in bn]
+        keys += [f"blocks.{i}.edge_inject.proj.0.weight", f"blocks.{i}.edge_inject.proj.0.bias",
+                 f"blocks.{i}.edge_inject.proj.2.weight", f"blocks.{i}.edge_inject.proj.2.bias"]
+    keys += ["head.0.weight", "head.0.bias"] + [f"head.1.{k}" for k in bn]
+    keys += ["head.4.weight", "head.4.bias", "head.6.weight", "head.6.bias"]
+    return keys
+
+
+def gcnnet_forward(state: dict, hidden: int, n_layers: int, x, edge_index, edge_attr):
+    """GCNTrimapNet (eval). state: {key: np.ndarray}. Returns (logits, probs) float32 (N,3)."""
+    L = lib()
+    keys = gcnnet_param_order(n_layers)
+    assert L.ggo_gcnnet_n_params(n_layers) == len(keys)
+    arrs = [f32(np.asarray(state[k])) for k in keys]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    x = f32(x)
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    ea = f32(edge_attr)
+    n, e = x.shape[0], ei.shape[1]
+    logits = np.empty((n, 3), np.float32)
+    probs = np.empty((n, 3), np.float32)
+    rc = L.ggo_gcnnet_forward(ptrs, _i(hidden), _i(n_layers), _i(n), _i(e), _p(x), _p(ei), _p(ea), _p(logits), _p(probs))
+    assert rc == 0
+    return logits, probs
+
+
 def gcn_aggregate(xw, edge_index, bias=None, gate=None, h=None):
     L = lib()
     xw = f32(xw)

@@ -84,3 +84,25 @@ def resgcn_forward(sd, n_layers, x, edge_index, edge_attr, batch=None):
     f = F.gelu(F.linear(F.layer_norm(z, (d,), sd["fuse.0.weight"], sd["fuse.0.bias"]),
                         sd["fuse.1.weight"], sd["fuse.1.bias"]))
     return F.linear(f, sd["head.weight"], sd["head.bias"])
+
+
+@torch.no_grad()
+def gcnnet_forward(sd, n_layers, x, edge_index, edge_attr):
+    """GCNTrimapNet.forward in eval mode (reference model.py:239-316, blocks :216-232, edge injection :142-162).
+    sd: state_dict of float32 CPU tensors with the reference keys."""
+    def bn(v, p):
+        return F.batch_norm(v, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+    n = x.size(0)
+    h = F.relu(bn(F.linear(bn(x, "in_norm.norm"), sd["input_proj.0.weight"], sd["input_proj.0.bias"]), "input_proj.1"))
+    all_h = [h]
+    for i in range(n_layers):
+        p = f"blocks.{i}."
+        c = F.relu(bn(gcn_conv(h, edge_index, sd[p + "conv.lin.weight"], sd[p + "conv.bias"]), p + "bn")) + h
+        g = torch.sigmoid(F.linear(F.relu(F.linear(edge_attr, sd[p + "edge_inject.proj.0.weight"], sd[p + "edge_inject.proj.0.bias"])),
+                                   sd[p + "edge_inject.proj.2.weight"], sd[p + "edge_inject.proj.2.bias"]))
+        h = c * scatter_mean(g, edge_index[1], n)
+        all_h.append(h)
+    z = F.relu(bn(F.linear(torch.cat(all_h, dim=-1), sd["head.0.weight"], sd["head.0.bias"]), "head.1"))
+    z = F.relu(F.linear(z, sd["head.4.weight"], sd["head.4.bias"]))
+    logits = F.linear(z, sd["head.6.weight"], sd["head.6.bias"])
+    return logits, torch.softmax(logits, dim=-1)
