@@ -21,7 +21,7 @@ import numpy as np
 
 from .grabcut import GrabCut, GrabCutConfig, Label
 from .graph_builder import GraphBuilder, SuperpixelGraphConfig, graphs_to_host, _check_image
-from .metrics import evaluate, SegmentationMetrics
+from .metrics import evaluate, evaluate_trimap, SegmentationMetrics, TrimapMetrics
 from .model import CLASS_BG, CLASS_FG, project_to_pixels  # noqa: F401
 
 
@@ -54,10 +54,9 @@ class SegmentationResult:
         _write_png(f"{prefix}_mask.png", self.binary_mask * 255)
         print(f"Saved outputs with prefix: {prefix}")
 
-    def evaluate_against(self, gt_mask: np.ndarray) -> SegmentationMetrics:
-        """Segmentation metrics against a ground-truth mask (the reference also returns
-        trimap metrics, which are evaluation extras outside this build's scope)."""
-        return evaluate(self.binary_mask, gt_mask)
+    def evaluate_against(self, gt_mask: np.ndarray) -> "tuple[SegmentationMetrics, TrimapMetrics]":
+        """Segmentation and trimap metrics against a ground-truth mask (reference pipeline.py:62-68)."""
+        return evaluate(self.binary_mask, gt_mask), evaluate_trimap(self.trimap, gt_mask)
 
 
 def guided_filter(guide: np.ndarray, src: np.ndarray, radius: int = 8, eps: float = 1e-3, device="cuda") -> np.ndarray:

@@ -83,8 +83,8 @@ def test_segment_returns_result_like_reference():
     assert result.overlay.shape == (100, 100, 3) and result.rgba.shape == (100, 100, 4)
     for key in ("graph_build", "data_prep", "gcn_inference", "grabcut", "postprocess"):
         assert key in result.timing
-    m = result.evaluate_against((np.indices((100, 100)).sum(0) % 2).astype(np.uint8))
-    assert 0 <= m.iou <= 1
+    m, tm = result.evaluate_against((np.indices((100, 100)).sum(0) % 2).astype(np.uint8))
+    assert 0 <= m.iou <= 1 and 0 <= tm.unknown_fraction <= 1
     r2 = pipeline.segment(img, edge_aware=False, keep_largest=True, refine_iters=1)
     assert r2.binary_mask.shape == (100, 100)
     rb = pipeline.segment_bbox(img, (10, 10, 80, 80))
