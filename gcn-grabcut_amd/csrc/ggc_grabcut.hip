@@ -90,7 +90,14 @@ __global__ void __launch_bounds__(256) k_gc_flags(GcDims d, const uint8_t* __res
         f |= is_bg(m) ? 8 : 16;           // class presence (for initGMMs' non-empty assert)
     }
     for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o, 64);
-    if ((threadIdx.x & 63) == 0 && f) atomicOr(&flags[b], f);
+    // one atomic per block and only for bits the cell does not hold yet: same-address atomics serialise in L2
+    __shared__ int s_f[4];
+    if ((threadIdx.x & 63) == 0) s_f[threadIdx.x >> 6] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        f = s_f[0] | s_f[1] | s_f[2] | s_f[3];
+        if (f & ~__hip_atomic_load(&flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&flags[b], f);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_gc_promote(GcDims d, const int32_t* __restrict__ flags, uint8_t* __restrict__ mask) {

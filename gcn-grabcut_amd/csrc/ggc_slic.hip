@@ -46,7 +46,13 @@ __global__ void __launch_bounds__(256) k_minmax(size_t n, const float* __restric
         lo = fminf(lo, v); hi = fmaxf(hi, v);
     }
     for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
-    if ((threadIdx.x & 63) == 0) {
+    // one atomic pair per block: every image has a single (min, max) cell and same-address atomics serialise in L2
+    __shared__ float s_lo[4], s_hi[4];
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+        hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
         atomicMin(&mm[2 * blockIdx.y], f2ord(lo));
         atomicMax(&mm[2 * blockIdx.y + 1], f2ord(hi));
     }
@@ -733,7 +739,7 @@ extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, co
 
     // 1-2: rescale + second Lab
     hipLaunchKernelGGL(k_minmax_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, mm);
-    hipLaunchKernelGGL(k_minmax, dim3(std::min(cdiv(P * 3, 256 * 8), 256), B), dim3(256), 0, st, P * 3, image, mm);
+    hipLaunchKernelGGL(k_minmax, dim3(std::min(cdiv(P * 3, 256 * 8), 48), B), dim3(256), 0, st, P * 3, image, mm);
     hipLaunchKernelGGL(k_lab2, dim3(cdiv(P, 256), B), dim3(256), 0, st, P, image, mm, rescale_input, img_a);
     GGC_LAUNCH_CHECK(ctx);
     // 4-5: Gaussian (y then x) and the 1/compactness scale
