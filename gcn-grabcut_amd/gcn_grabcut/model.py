@@ -273,9 +273,13 @@ if _TORCH:
             super().__init__()
             if in_channels != N_NODE_FEATS or edge_channels != N_EDGE_FEATS or n_classes != 3:
                 raise ValueError("the MI355X kernels are built for 19 node features, 5 edge features and 3 classes")
-            if hidden_channels not in (32, 64, 96, 128):
-                raise ValueError("hidden_channels must be one of 32, 64, 96, 128 (template instantiations of the HIP kernels)")
+            if hidden_channels % 2 or not 2 <= hidden_channels <= 128:
+                raise ValueError("hidden_channels must be even and at most 128 (the HIP kernels are built for widths up to 128)")
             self.n_classes, self.hidden_channels, self.n_layers = n_classes, hidden_channels, n_layers
+            # The MFMA tiling needs a multiple of 32: other widths (the reference's tests use 16) run zero-padded to
+            # the next multiple.  Padded channels carry exact zeros through every layer (zero weight rows / columns,
+            # identity BatchNorm statistics), so the result is the unpadded model's, bit for bit.
+            self._kernel_width = -(-hidden_channels // 32) * 32
             self.in_norm = _InputNorm(in_channels)
             self.input_proj = nn.Sequential(nn.Linear(in_channels, hidden_channels), nn.BatchNorm1d(hidden_channels), nn.ReLU())
             self.blocks = nn.ModuleList([_ResGCNBlock(hidden_channels, edge_channels) for _ in range(n_layers)])
@@ -297,14 +301,41 @@ if _TORCH:
             fp = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
             if self._uploaded.get(id(ctx)) == fp:
                 return
-            ctx.call("ggc_gcnnet_configure", self.hidden_channels, self.n_layers)
+            ctx.call("ggc_gcnnet_configure", self._kernel_width, self.n_layers)
             for k, v in sd.items():
                 if not v.dtype.is_floating_point:
                     continue   # num_batches_tracked
-                a = v.detach().to(device="cpu", dtype=torch.float32).contiguous().numpy()
+                a = self._padded(k, v.detach().to(device="cpu", dtype=torch.float32).contiguous().numpy())
                 ctx.call("ggc_gcnnet_load_weight", k.encode(), a.ctypes.data, a.size)
             ctx.call("ggc_gcnnet_ready")
             self._uploaded[id(ctx)] = fp
+
+        def _padded(self, key: str, a: np.ndarray) -> np.ndarray:
+            """Tensor `key` at the kernels' width: zero rows / columns, and BatchNorm statistics (mean 0, var 1, weight 1,
+            bias 0) that map the padded zeros to zeros."""
+            d, w, n = self.hidden_channels, self._kernel_width, self.n_layers
+            if d == w or key.startswith("in_norm."):
+                return a
+
+            def pad(x, shape, fill=0.0):
+                out = np.full(shape, fill, np.float32)
+                out[tuple(slice(0, s) for s in x.shape)] = x
+                return np.ascontiguousarray(out)
+
+            if key == "head.0.weight":                         # [d, d (n+1)]: one block per concatenated state
+                out = np.zeros((w, w * (n + 1)), np.float32)
+                for s in range(n + 1):
+                    out[:d, s * w:s * w + d] = a[:, s * d:(s + 1) * d]
+                return out
+            if key == "head.4.weight": return pad(a, (w // 2, w))
+            if key == "head.4.bias": return pad(a, (w // 2,))
+            if key == "head.6.weight": return pad(a, (3, w // 2))
+            if key == "head.6.bias": return a
+            if key.endswith("running_var") or (a.ndim == 1 and key.endswith(".weight")):   # BatchNorm var / weight
+                return pad(a, (w,), 1.0)
+            if a.ndim == 1: return pad(a, (w,))
+            if key.endswith("edge_inject.proj.0.weight") or key == "input_proj.0.weight": return pad(a, (w, a.shape[1]))
+            return pad(a, (w, w))
 
         def _run(self, data, want_logits: bool, want_probs: bool):
             if self.training:
