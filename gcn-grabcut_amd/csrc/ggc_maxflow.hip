@@ -330,6 +330,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     // schedule measured on MI355X (tools/mf_sweep.sh)
     static const int n_launch = env_int("GGC_MF_PR_LAUNCHES", 24), n_inner = env_int("GGC_MF_PR_INNER", 8);
     static const int n_launch0 = env_int("GGC_MF_PR_LAUNCHES0", 12);
+    static const int relax_rep = env_int("GGC_MF_RELAX_REP", 4);         // relabel launches per read-back of the next list's size
     static const int tail_active = env_int("GGC_MF_TAIL_ACTIVE", 4000), tail_launch = env_int("GGC_MF_TAIL_LAUNCHES", 64);
     const int max_rounds = 4096;
     auto t_prev = std::chrono::steady_clock::now();
@@ -350,7 +351,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
                                rl_list[0], rl_flag[0], rl_cnt);
             int phase = 0;
             for (int guard = 0; guard < 100000; ++guard) {
-                for (int rep = 0; rep < 4; ++rep, ++phase)
+                for (int rep = 0; rep < relax_rep; ++rep, ++phase)
                     hipLaunchKernelGGL(k_mf_relax_list, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
                                        rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
                 GGC_LAUNCH_CHECK(ctx);

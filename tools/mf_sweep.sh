@@ -1,11 +1,11 @@
 #!/bin/bash
-# experiment helper: late-round schedule with 32x32 push tiles (full-pipeline bench)
-for cfg in ${CFGS:-"0 24 32" "1 24 32" "1 16 32" "1 32 32" "1 16 64" "1 12 32"}; do
+# experiment helper: relabel launches per host read-back, and lanes (full-pipeline bench)
+for cfg in ${CFGS:-"4 4" "6 4" "8 4" "12 4" "8 6" "12 8"}; do
   set -- $cfg
-  GGC_MF_TALL=$1 GGC_MF_TALL_LAUNCHES=$2 GGC_MF_TALL_INNER=$3 python bench.py --steps 3 --warmup 1 --cpu-sample 0 2>&1 | tail -1 > /tmp/mf.json
+  GGC_MF_RELAX_REP=$1 python bench.py --steps 3 --warmup 1 --cpu-sample 0 --lanes $2 2>&1 | tail -1 > /tmp/mf.json
   python - "$cfg" <<'PY'
 import json,sys
 d=json.load(open("/tmp/mf.json")); s=d["stage_ms_per_step"]
-print("tall launches inner",sys.argv[1],"img/s",d["value"],"ms_per_step",d["ms_per_step"],"relabel",s["maxflow_relabel"],"push",s["maxflow_push"])
+print("relax_rep lanes",sys.argv[1],"img/s",d["value"],"ms_per_step",d["ms_per_step"])
 PY
 done
