@@ -204,6 +204,8 @@ def main() -> None:
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload, batch_size),
             "bytes_per_launch": b_launch, "avg_launch_us": round(agg_avg_s * 1e6, 2), "launches": launches,
             "event_pair_overhead_us": round(ctx.profile_query("#event_pair_overhead")[1] * 1e3, 2),
+            # informational: bytes of all gathered neighbour rows per second; they are served from LDS
+            "effective_gather_gbs": round((n_edges + n_nodes) * HIDDEN * 4 / agg_avg_s / 1e9, 1) if launches else 0.0,
         }
         stage_ms = {k: round(v[1] / args.steps, 3) for k, v in prof.items() if v[0]}
 
@@ -219,15 +221,19 @@ def main() -> None:
                 t1 = time.perf_counter()
                 ref = [orc.segment(host_imgs[i], sd, HIDDEN, LAYERS, n_segments=N_SEGMENTS, seed=i) for i in range(n_s)]
                 dt = time.perf_counter() - t1
-                ious, dl = [], 0.0
+                ious, dl, ei_ok = [], 0.0, []
+                esrc, edst = g.edge_src.cpu().numpy().astype(np.int64), g.edge_dst.cpu().numpy().astype(np.int64)
                 for i, r in enumerate(ref):
                     n0, n1 = int(g.node_ptr_host[i]), int(g.node_ptr_host[i + 1])
+                    e0, e1 = int(g.edge_ptr_host[i]), int(g.edge_ptr_host[i + 1])
+                    ei_ok.append(np.array_equal(np.stack([esrc[e0:e1], edst[e0:e1]]) - n0, r["graph"]["edge_index"]))
                     if n1 - n0 == r["probs"].shape[0]:
                         dl = max(dl, float(np.abs(probs_g[n0:n1] - r["probs"]).max()))
                     ious.append(orc.iou(bin_g[i], r["binary_mask"]) if r["binary_mask"].any() or bin_g[i].any() else 1.0)
                 parity = {
                     "sample": n_s,
                     "label_map_exact_pct": round(100.0 * float(np.mean([np.array_equal(seg_g[i], ref[i]["segments"]) for i in range(n_s)])), 2),
+                    "edge_index_exact_pct": round(100.0 * float(np.mean(ei_ok)), 2),
                     "trimap_pixel_match_pct": round(100.0 * float(np.mean([(tri_g[i] == ref[i]["trimap"]).mean() for i in range(n_s)])), 4),
                     "mask_exact_pct": round(100.0 * float(np.mean([np.array_equal(bin_g[i], ref[i]["binary_mask"]) for i in range(n_s)])), 2),
                     "max_abs_dprob": dl, "mean_mask_iou": round(float(np.mean(ious)), 6), "min_mask_iou": round(float(np.min(ious)), 6),
