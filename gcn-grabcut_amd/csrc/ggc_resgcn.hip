@@ -18,6 +18,7 @@
 // gives the per-graph ranges.  The destination CSR (row_ptr, col, eid) is
 // built once per forward, stable in edge order, and reused by all 8 gathers.
 #include "ggc_internal.h"
+#include <atomic>
 #include <cmath>
 #include <type_traits>
 
@@ -973,12 +974,12 @@ static int prepare_weights(ggc_ctx* ctx) {
 
 template <int D, int MODE>
 static int launch_gemm(ggc_ctx* ctx, hipStream_t st, int N, const GemmArgs& a) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};      // contexts on other host threads (GrabCut lanes use none of this, but be safe)
     const size_t lds = (size_t)D * D * sizeof(float);
-    if (!attr_set && lds > 48 * 1024) {
+    if (!attr_set.load(std::memory_order_acquire) && lds > 48 * 1024) {
         GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<D, MODE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     ProfScope prof(ctx, st, MODE == 0 ? "gcn_gemm" : MODE == 1 ? "sage_gemm" : MODE == 2 ? "head_gemm" : "plain_gemm");
     hipLaunchKernelGGL((k_gemm<D, MODE>), dim3(cdiv(N, 128)), dim3(256), lds, st, N, a);
@@ -990,11 +991,11 @@ template <int D, int MODE, int SW, bool GATED>
 static int launch_aggregate_graph_t(ggc_ctx* ctx, hipStream_t st, int G, const int32_t* node_ptr, const int32_t* pack,
                                     const float* xw, const int32_t* row_ptr, const int32_t* col, const float* dis,
                                     const float* bias, const float* gate, const float* h, float* out) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
         GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate_graph<D, MODE, SW, GATED>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, AggGraph<SW>::LDS));
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_aggregate_graph<D, MODE, SW, GATED>), dim3(cdiv(G, 8) * 8 * (D / SW)), dim3(512), AggGraph<SW>::LDS, st,
                        G, node_ptr, xw, row_ptr, col, pack, dis, bias, gate, h, out);

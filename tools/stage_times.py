@@ -7,9 +7,10 @@ from gcn_grabcut import GCNGrabCutPipeline, SuperpixelGraphConfig, ResGCNNet
 from gcn_grabcut.synthetic import synthetic_batch
 torch.manual_seed(0)
 B = int(os.environ.get("B", "256"))
+H, W, NSEG = int(os.environ.get("H", "300")), int(os.environ.get("W", "400")), int(os.environ.get("NSEG", "600"))
 model = ResGCNNet().eval()
-pipe = GCNGrabCutPipeline(model, sp_config=SuperpixelGraphConfig(n_segments=600), grabcut_lanes=int(os.environ.get("LANES", "4")))
-bgr = torch.from_numpy(synthetic_batch(B, 300, 400, 3)).cuda()
+pipe = GCNGrabCutPipeline(model, sp_config=SuperpixelGraphConfig(n_segments=NSEG), grabcut_lanes=int(os.environ.get("LANES", "4")))
+bgr = torch.from_numpy(synthetic_batch(B, H, W, 3)).cuda()
 eng, cfg = pipe._eng, pipe.sp_config
 def T(f):
     torch.cuda.synchronize(); t = time.perf_counter(); r = f(); torch.cuda.synchronize(); return r, (time.perf_counter() - t) * 1e3
