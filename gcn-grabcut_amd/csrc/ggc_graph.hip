@@ -16,6 +16,7 @@
 //  * ggc_graph_count synchronises twice (node counts, pair counts) so that the
 //    packed outputs can be sized exactly; ggc_graph_fill only copies.
 #include "ggc_internal.h"
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -97,81 +98,138 @@ __global__ void k_bbox_init(size_t n, int4* bbox) {
 }
 
 // ---- K2: region statistics, one lane per region, raster order, f64 sums
+// The sums must be float64 running sums in raster order (= np.bincount(weights=...)), so a lane owns a region and walks
+// its bounding box.  Read straight from global memory that walk moved 15x the bytes it needed (PMC: 15.8 GB per launch
+// against 1 GB of inputs — 64 lanes, 64 different cache lines per load).  Instead the wave stages one image ROW of the
+// union of its 64 regions' boxes in LDS with coalesced loads (labels of the rows above / below too, for the boundary
+// test), and every lane scans its own x-range of that row from LDS.  Same visits in the same order, every byte loaded
+// about twice (overlap of neighbouring waves' unions).
+struct StatsAcc {
+    double cnt = 0, sl[3] = {0, 0, 0}, sl2[3] = {0, 0, 0}, sh[3] = {0, 0, 0};
+    double sy = 0, sx = 0, syd = 0, sxd = 0, sb = 0, sg1 = 0, sgn = 0;
+};
+
 __global__ void __launch_bounds__(64) k_stats(GDims d, const int32_t* __restrict__ seg,
                                               const int32_t* __restrict__ n_nodes,
                                               const float* __restrict__ lab, const float* __restrict__ hsv,
                                               const float* __restrict__ grad, const int4* __restrict__ bbox,
                                               const int32_t* __restrict__ border,
                                               const uint32_t* __restrict__ gmax, RegionStats* __restrict__ out) {
-    const int b = blockIdx.y;
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= n_nodes[b]) return;
+    extern __shared__ float s_row[];          // [3][Wu] labels (rows y-1, y, y+1) | [Wu][3] lab | [Wu][3] hsv | [Wu] grad | [Wu] grad/max
+                                              // | [Wu] (float)x/W | [Wu] (double)x/W: the quotients are per pixel / per column, not per visit
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const int N = n_nodes[b];
+    const int r0 = blockIdx.x * 64;
+    if (r0 >= N) return;
+    const int r = r0 + lane;
+    const bool live = r < N;
     const int H = d.H, W = d.W;
     const size_t P = (size_t)H * W;
     const int32_t* sg = seg + (size_t)b * P;
     const float* lb = lab + (size_t)b * P * 3;
     const float* hv = hsv + (size_t)b * P * 3;
     const float* gr = grad + (size_t)b * P;
-    const int4 bb = bbox[(size_t)b * d.Nmax + r];
+    const int4 bb = live ? bbox[(size_t)b * d.Nmax + r] : make_int4(INT32_MAX, 0, INT32_MAX, 0);
     const float gden = (float)((double)ord2f_g(gmax[b]) + 1e-6);
-    double cnt = 0, sl[3] = {0, 0, 0}, sl2[3] = {0, 0, 0}, sh[3] = {0, 0, 0};
-    double sy = 0, sx = 0, syd = 0, sxd = 0, sb = 0, sg1 = 0, sgn = 0;
-    // The scan is a chain of dependent loads (label -> compare -> next pixel) on a kernel with few waves: read the
-    // labels of 8 pixels ahead in one go so that the chain is paid once per 8 pixels.  Visiting order is unchanged.
-    constexpr int SCAN = 8;
-    for (int y = bb.x; y < bb.y; ++y) {
-        const size_t row = (size_t)y * W;
-        for (int x0 = bb.z; x0 < bb.w; x0 += SCAN) {
-          int sv[SCAN];
+    // union of the wave's boxes
+    int uy0 = bb.y > bb.x ? bb.x : INT32_MAX, uy1 = bb.y > bb.x ? bb.y : 0;
+    int ux0 = bb.w > bb.z ? bb.z : INT32_MAX, ux1 = bb.w > bb.z ? bb.w : 0;
 #pragma unroll
-          for (int j = 0; j < SCAN; ++j) sv[j] = (x0 + j < bb.w) ? sg[row + x0 + j] : -1;
+    for (int o = 32; o > 0; o >>= 1) {
+        uy0 = min(uy0, __shfl_xor(uy0, o, 64)); uy1 = max(uy1, __shfl_xor(uy1, o, 64));
+        ux0 = min(ux0, __shfl_xor(ux0, o, 64)); ux1 = max(ux1, __shfl_xor(ux1, o, 64));
+    }
+    const int Wu = max(ux1 - ux0, 0);
+    int32_t* s_seg = reinterpret_cast<int32_t*>(s_row);            // 3 rows, slot = (y + 1) % 3 rotates
+    float* s_lab = s_row + 3 * (size_t)Wu;
+    float* s_hsv = s_lab + 3 * (size_t)Wu;
+    float* s_grd = s_hsv + 3 * (size_t)Wu;
+    float* s_gn = s_grd + Wu;
+    float* s_xf = s_gn + Wu;
+    double* s_xd = reinterpret_cast<double*>(s_xf + Wu + (Wu & 1));          // 8-byte aligned: 12 Wu + (Wu & 1) floats precede it
+    for (int i = lane; i < Wu; i += 64) { s_xf[i] = (float)(ux0 + i) / (float)W; s_xd[i] = (double)(ux0 + i) / (double)W; }
+    // Rows are staged by LDS-DMA (global_load_lds, 4 B per lane, 256 B per instruction): a single wave cannot hide
+    // the latency of load -> store loops, but it can have a whole row of DMA pieces in flight and wait once.
+    auto dma_row = [&](const void* src, void* dst, int n_words) {   // n_words 4-byte words, contiguous on both sides
+        for (int i = 0; i < n_words; i += 64)
+            if (i + lane < n_words)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const uint32_t*)src + i + lane),
+                                                 (__attribute__((address_space(3))) void*)((uint32_t*)dst + i), 4, 0, 0);
+    };
+    auto load_seg_row = [&](int y) {                                // labels of image row y (or -1 outside) into its slot
+        int32_t* dst = s_seg + (size_t)((y + 3) % 3) * Wu;
+        if (y >= 0 && y < H) dma_row(sg + (size_t)y * W + ux0, dst, Wu);
+        else for (int i = lane; i < Wu; i += 64) dst[i] = -1;
+    };
+    StatsAcc a;
+    if (uy1 > uy0 && Wu > 0) {
+        load_seg_row(uy0 - 1);
+        load_seg_row(uy0);
+        for (int y = uy0; y < uy1; ++y) {
+            load_seg_row(y + 1);
+            const size_t row = (size_t)y * W + ux0;
+            dma_row(lb + 3 * row, s_lab, 3 * Wu);
+            dma_row(hv + 3 * row, s_hsv, 3 * Wu);
+            dma_row(gr + row, s_grd, Wu);
+            const double yf = (double)((float)y / (float)H), yd = (double)y / (double)H;
+            __builtin_amdgcn_s_waitcnt(0);                          // every DMA piece of this row has landed
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < Wu; i += 64) s_gn[i] = s_grd[i] / gden;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (live && y >= bb.x && y < bb.y) {
+                const int32_t* cur = s_seg + (size_t)((y + 3) % 3) * Wu;
+                const int32_t* up = s_seg + (size_t)((y + 2) % 3) * Wu;
+                const int32_t* dn = s_seg + (size_t)((y + 4) % 3) * Wu;
+                for (int x = bb.z; x < bb.w; ++x) {
+                    const int i = x - ux0;
+                    if (cur[i] != r) continue;
+                    a.cnt += 1.0;
 #pragma unroll
-          for (int j = 0; j < SCAN; ++j) {
-            if (sv[j] != r) continue;
-            const int x = x0 + j;
-            const size_t p = row + x;
-            cnt += 1.0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v = lb[3 * p + c];
-                sl[c] += (double)v;
-                sl2[c] += (double)(v * v);
-                sh[c] += (double)hv[3 * p + c];
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = s_lab[3 * i + c];
+                        a.sl[c] += (double)v;
+                        a.sl2[c] += (double)(v * v);
+                        a.sh[c] += (double)s_hsv[3 * i + c];
+                    }
+                    a.sy += yf;
+                    a.sx += (double)s_xf[i];
+                    a.syd += yd;
+                    a.sxd += s_xd[i];
+                    // find_boundaries(mode="inner"): 4-neighbourhood max != min, and label != 0
+                    int mx = r, mn = r;
+                    if (y > 0) { const int u = up[i]; mx = max(mx, u); mn = min(mn, u); }
+                    if (y < H - 1) { const int u = dn[i]; mx = max(mx, u); mn = min(mn, u); }
+                    // the left / right neighbours can lie just outside the staged columns: read those from memory
+                    if (x > 0) { const int u = i > 0 ? cur[i - 1] : sg[(size_t)y * W + x - 1]; mx = max(mx, u); mn = min(mn, u); }
+                    if (x < W - 1) { const int u = i + 1 < Wu ? cur[i + 1] : sg[(size_t)y * W + x + 1]; mx = max(mx, u); mn = min(mn, u); }
+                    if (mx != mn && r != 0) a.sb += 1.0;
+                    a.sg1 += (double)s_grd[i];
+                    a.sgn += (double)s_gn[i];
+                }
             }
-            sy += (double)((float)y / (float)H);
-            sx += (double)((float)x / (float)W);
-            syd += (double)y / (double)H;
-            sxd += (double)x / (double)W;
-            // find_boundaries(mode="inner"): 4-neighbourhood max != min, and label != 0
-            int mx = r, mn = r;
-            if (y > 0) { const int u = sg[p - W]; mx = max(mx, u); mn = min(mn, u); }
-            if (y < H - 1) { const int u = sg[p + W]; mx = max(mx, u); mn = min(mn, u); }
-            if (x > 0) { const int u = sg[p - 1]; mx = max(mx, u); mn = min(mn, u); }
-            if (x < W - 1) { const int u = sg[p + 1]; mx = max(mx, u); mn = min(mn, u); }
-            if (mx != mn && r != 0) sb += 1.0;
-            const float g = gr[p];
-            sg1 += (double)g;
-            sgn += (double)(g / gden);
-          }
+            __builtin_amdgcn_wave_barrier();       // everyone is done with this row before its buffers are overwritten
         }
     }
+    if (!live) return;
     RegionStats s;
-    s.cnt = (float)cnt;
+    s.cnt = (float)a.cnt;
     s.safe = s.cnt > 1.0f ? s.cnt : 1.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float m = (float)sl[c] / s.safe;
-        const float sq = (float)sl2[c] / s.safe;
+        const float m = (float)a.sl[c] / s.safe;
+        const float sq = (float)a.sl2[c] / s.safe;
         float v = sq - m * m;
         if (!(v > 0.0f)) v = (v != v) ? v : 0.0f;
         s.mlab[c] = m; s.slab[c] = sqrtf(v);
-        s.mhsv[c] = (float)sh[c] / s.safe;
+        s.mhsv[c] = (float)a.sh[c] / s.safe;
     }
-    s.cy = (float)sy / s.safe; s.cx = (float)sx / s.safe;
-    s.pcy = (float)(syd / (double)s.safe); s.pcx = (float)(sxd / (double)s.safe);
-    s.bpx = (float)sb;
-    s.mgrad = (float)sg1 / s.safe;
-    s.mgn = (float)sgn / s.safe;
+    s.cy = (float)a.sy / s.safe; s.cx = (float)a.sx / s.safe;
+    s.pcy = (float)(a.syd / (double)s.safe); s.pcx = (float)(a.sxd / (double)s.safe);
+    s.bpx = (float)a.sb;
+    s.mgrad = (float)a.sg1 / s.safe;
+    s.mgn = (float)a.sgn / s.safe;
     s.area = s.cnt / (float)((double)H * (double)W);
     s.border = (float)border[(size_t)b * d.Nmax + r];
     out[(size_t)b * d.Nmax + r] = s;
@@ -643,7 +701,15 @@ extern "C" int ggc_graph_count(ggc_ctx* ctx, ggc_stream stream, int B, int H, in
     hipLaunchKernelGGL(k_bbox, dim3(cdiv(W, 64), cdiv(H, BBOX_ROWS), B), dim3(256), 0, st, d, segments, grad, bbox, border, gmax);
     {
         ProfScope prof(ctx, st, "graph_stats");
-        hipLaunchKernelGGL(k_stats, dim3(cdiv(Nmax, 64), B), dim3(64), 0, st, d, segments, n_nodes, lab, hsv, grad,
+        const size_t stats_lds = ((size_t)W * 15 + 2) * sizeof(float);  // 3 label rows, lab, hsv, grad, grad/max, x/W as f32 and f64
+        static std::atomic<int> stats_lds_set{0};
+        if ((int)stats_lds > 48 * 1024 && stats_lds_set.load(std::memory_order_acquire) < (int)stats_lds) {
+            GGC_REQUIRE(ctx, stats_lds <= 160 * 1024, GGC_E_UNSUPPORTED, "image width %d too large for the statistics kernel", W);
+            GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stats), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)stats_lds));
+            stats_lds_set.store((int)stats_lds, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(k_stats, dim3(cdiv(Nmax, 64), B), dim3(64), stats_lds, st, d, segments, n_nodes, lab, hsv, grad,
                            bbox, border, gmax, stats);
     }
     hipLaunchKernelGGL(k_adj, pix, dim3(256), 0, st, d, segments, dense);
