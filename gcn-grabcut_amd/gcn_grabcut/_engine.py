@@ -196,6 +196,13 @@ class Engine:
                       int(seed), binary.data_ptr())
         return binary, mask, bgd, fgd
 
+    def convert_color8(self, bgr: torch.Tensor, space: str) -> torch.Tensor:
+        """(…,3) uint8 BGR -> 8-bit HSV / Lab in the style of cv2.cvtColor (ggc_convert_color8)."""
+        out = torch.empty_like(bgr)
+        self.ctx.call("ggc_convert_color8", self._stream(), int(bgr.numel() // 3), bgr.data_ptr(), {"hsv": 0, "lab": 1}[space],
+                      out.data_ptr())
+        return out
+
     def clean_mask(self, mask, min_area_ratio=0.002, keep_largest=False) -> torch.Tensor:
         b, h, w = mask.shape
         out = torch.empty_like(mask)

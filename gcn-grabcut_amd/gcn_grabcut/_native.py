@@ -57,6 +57,7 @@ SIGNATURES = {
     "ggc_mask_iou": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "ggc_region_label_stats": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ggc_eval_counts": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "ggc_convert_color8": [_vp, _vp, _i64, _vp, _i, _vp],
 }
 _RESTYPES = {"ggc_last_error": C.c_char_p}
 

@@ -61,15 +61,18 @@ class GrabCut:
         self._fgd = np.zeros((1, 65), np.float64)
         self.history: List[GrabCutSnapshot] = []
         self._eng = get_engine(device)
-        self._proc = self._eng.to_device(self._preprocess(image)[None])
+        self._proc = self._preprocess(image)
 
-    def _preprocess(self, image: np.ndarray) -> np.ndarray:
+    def _preprocess(self, image: np.ndarray):
+        """BGR uint8 -> the (1,H,W,3) uint8 device image GrabCut works on (reference grabcut.py:73-79).  hsv / lab are
+        8-bit conversions in the style of cv2.cvtColor (ggc_convert_color8; parity with OpenCV unpinned)."""
         cs = self.config.color_space.lower()
+        dev = self._eng.to_device(np.ascontiguousarray(image)[None])
         if cs in ("hsv", "lab"):
-            raise NotImplementedError(
-                f"color_space='{cs}' needs OpenCV's 8-bit BGR2{cs.upper()} conversion, which is not part of "
-                "the MI355X hot path yet (SURVEY section 8(f) rank 3); use 'rgb'")
-        return np.ascontiguousarray(image)
+            return self._eng.convert_color8(dev, cs)
+        if cs != "rgb":
+            raise ValueError(f"unknown color_space '{cs}': rgb | hsv | lab")
+        return dev
 
     def _run(self, mask: Optional[np.ndarray], n_iter: int, mode: int, rect=None) -> np.ndarray:
         import torch

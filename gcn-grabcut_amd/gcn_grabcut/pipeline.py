@@ -141,8 +141,9 @@ class GCNGrabCutPipeline:
         """bgr: (B,H,W,3) uint8 tensor on the pipeline's device.  Returns device tensors."""
         import torch
         eng, cfg = self._eng, self.sp_config
-        if self.gc_config.color_space.lower() != "rgb":
-            raise NotImplementedError("only color_space='rgb' is on the MI355X hot path")
+        cs = self.gc_config.color_space.lower()
+        if cs not in ("rgb", "hsv", "lab"):
+            raise ValueError(f"unknown color_space '{cs}': rgb | hsv | lab")
         if not cfg.use_lab:
             raise NotImplementedError("use_lab=False is not on the MI355X hot path")
 
@@ -171,9 +172,10 @@ class GCNGrabCutPipeline:
         t = tick()
         mask = trimap.clone()
         lanes = self.grabcut_lanes if bgr.size(0) >= 8 * max(self.grabcut_lanes, 1) else 1
-        binary, mask, bgd, fgd = eng.grabcut_lanes(bgr, mask, self.gc_config.n_iter, 0, self.gc_config.seed, lanes)
+        gc_img = bgr if cs == "rgb" else eng.convert_color8(bgr, cs)      # reference grabcut.py:73-79
+        binary, mask, bgd, fgd = eng.grabcut_lanes(gc_img, mask, self.gc_config.n_iter, 0, self.gc_config.seed, lanes)
         if refine_iters > 0:
-            binary, mask, bgd, fgd = eng.grabcut_lanes(bgr, mask, refine_iters, 2, self.gc_config.seed, lanes, bgd, fgd)
+            binary, mask, bgd, fgd = eng.grabcut_lanes(gc_img, mask, refine_iters, 2, self.gc_config.seed, lanes, bgd, fgd)
         if timing is not None:
             timing["grabcut"] = tick() - t
 

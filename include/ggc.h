@@ -265,6 +265,12 @@ int ggc_compose_outputs(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
 int ggc_mask_iou(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                  const uint8_t* pred, const uint8_t* gt, double* iou, uint64_t* counts);
 
+/* C7 — 8-bit colour spaces for GrabCutConfig.color_space (reference grabcut.py:73-79: cv2.cvtColor(BGR2HSV / BGR2Lab)
+ * on uint8 images).  mode 0 = HSV (H in [0,180), OpenCV's fixed-point scheme), mode 1 = Lab
+ * (L*255/100, a+128, b+128 of the float64 CIELAB, rounded).  OpenCV is absent here: parity with it is unpinned.
+ *   bgr, out [dev] u8 [n_pixels,3] */
+int ggc_convert_color8(ggc_ctx* ctx, ggc_stream stream, int64_t n_pixels, const uint8_t* bgr, int mode, uint8_t* out);
+
 /* R1 — integer tallies behind metrics.evaluate / boundary_f1 / evaluate_trimap (metrics.py:58-129, 152-201), per
  * image.  counts [dev] u64 [B,14]:
  *   0 tp 1 fp 2 fn (pred / gt != 0)

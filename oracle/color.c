@@ -87,3 +87,45 @@ void ggo_preprocess(int H, int W, const uint8_t* bgr,
         }
     }
 }
+
+/* 8-bit colour spaces for GrabCutConfig.color_space (reference grabcut.py:73-79 calls cv2.cvtColor(BGR2HSV / BGR2Lab) on
+ * uint8 images).  OpenCV is absent: PARITY UNPINNED.
+ *   mode 0, HSV: OpenCV's integer RGB2HSV_b as recalled from color_hsv.simd.hpp — H in [0,180), fixed point with
+ *     sdiv_table[v] = round((255 << 12) / v), hdiv_table[d] = round((180 << 12) / (6 d)).
+ *   mode 1, Lab: the documented 8-bit convention L <- L*255/100, a <- a+128, b <- b+128 applied to the float64 CIELAB of
+ *     ggo_preprocess (D65, same matrix), rounded half up and clamped; OpenCV's own fixed-point tables may differ by one
+ *     level. */
+void ggo_convert_color8(size_t n, const uint8_t* bgr, int mode, uint8_t* out) {
+    if (mode == 0) {
+        for (size_t p = 0; p < n; ++p) {
+            const int b = bgr[3 * p + 0], g = bgr[3 * p + 1], r = bgr[3 * p + 2];
+            int v = b > g ? b : g; if (r > v) v = r;
+            int vmin = b < g ? b : g; if (r < vmin) vmin = r;
+            const int diff = v - vmin;
+            const int sdiv = v ? (int)rint((double)(255 << 12) / (double)v) : 0;
+            const int hdiv = diff ? (int)rint((double)(180 << 12) / (6.0 * (double)diff)) : 0;
+            const int s = (diff * sdiv + (1 << 11)) >> 12;
+            int h = (v == r) ? (g - b) : (v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff);
+            h = (h * hdiv + (1 << 11)) >> 12;
+            if (h < 0) h += 180;
+            out[3 * p + 0] = (uint8_t)h; out[3 * p + 1] = (uint8_t)s; out[3 * p + 2] = (uint8_t)v;
+        }
+        return;
+    }
+    double lut[256];
+    for (int u = 0; u < 256; ++u) lut[u] = srgb_to_linear(u);
+    for (size_t p = 0; p < n; ++p) {
+        const double B = lut[bgr[3 * p + 0]], G = lut[bgr[3 * p + 1]], R = lut[bgr[3 * p + 2]];
+        const double X = R * 0.412453 + G * 0.357580 + B * 0.180423;
+        const double Y = R * 0.212671 + G * 0.715160 + B * 0.072169;
+        const double Z = R * 0.019334 + G * 0.119193 + B * 0.950227;
+        const double fx = lab_f(X / 0.95047), fy = lab_f(Y / 1.0), fz = lab_f(Z / 1.08883);
+        const double v[3] = {(116.0 * fy - 16.0) * 255.0 / 100.0, 500.0 * (fx - fy) + 128.0, 200.0 * (fy - fz) + 128.0};
+        for (int c = 0; c < 3; ++c) {
+            double q = floor(v[c] + 0.5);
+            if (q < 0.0) q = 0.0;
+            if (q > 255.0) q = 255.0;
+            out[3 * p + c] = (uint8_t)q;
+        }
+    }
+}

@@ -27,6 +27,7 @@
  */
 #ifndef GGC_ORACLE_H
 #define GGC_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -34,6 +35,8 @@ extern "C" {
 #endif
 
 /* ---- shared deterministic math (restated independently in the HIP code) ---- */
+/* 8-bit HSV (mode 0) / Lab (mode 1) of a BGR image, for GrabCutConfig.color_space (grabcut.py:73-79); see oracle/color.c */
+void ggo_convert_color8(size_t n, const uint8_t* bgr, int mode, uint8_t* out);
 double ggo_cbrt(double a);        /* a > 0 */
 double ggo_pow24(double a);       /* a^2.4, a > 0 */
 double ggo_exp(double x);

@@ -351,6 +351,15 @@ def iou(pred, gt):
     return float(L.ggo_iou(_i(pred.size), _p(pred), _p(gt)))
 
 
+def convert_color8(bgr, mode):
+    """uint8 HSV (mode "hsv") or Lab ("lab") of a BGR uint8 image (oracle/color.c; parity with OpenCV unpinned)."""
+    L = lib()
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    out = np.empty_like(bgr)
+    L.ggo_convert_color8(C.c_size_t(bgr.size // 3), _p(bgr), _i({"hsv": 0, "lab": 1}[mode]), _p(out))
+    return out
+
+
 def eval_counts(pred, gt, trimap=None, width=3):
     """int64[14] tallies behind evaluate / boundary_f1 / evaluate_trimap (see oracle/postproc.c)."""
     L = lib()

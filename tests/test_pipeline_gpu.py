@@ -139,8 +139,30 @@ def test_grabcut_class_like_reference(oracle):
         gc2.run_with_trimap(np.zeros((10, 10), np.uint8))
     with pytest.raises(RuntimeError):
         GrabCut(img).refine(1)
-    with pytest.raises(NotImplementedError):
-        GrabCut(img, GrabCutConfig(color_space="hsv"))
+    with pytest.raises(ValueError):
+        GrabCut(img, GrabCutConfig(color_space="xyz"))
+
+
+@pytest.mark.parametrize("cs", ["rgb", "hsv", "lab"])
+def test_grabcut_color_spaces_like_reference(oracle, cs):
+    # reference tests/test.py:52-57, plus: the device conversion equals the oracle's byte for byte and GrabCut on the
+    # converted image equals the oracle's GrabCut on the oracle's conversion
+    from gcn_grabcut import GCNGrabCutPipeline, ResGCNNet
+    from gcn_grabcut._engine import get_engine
+    from gcn_grabcut.grabcut import GrabCut, GrabCutConfig
+    from gcn_grabcut.synthetic import synthetic_image
+    img = synthetic_image(96, 128, 321)
+    gc = GrabCut(img, GrabCutConfig(n_iter=2, color_space=cs))
+    m = gc.run_with_bbox((10, 10, 100, 70))
+    assert m.shape == (96, 128) and set(np.unique(m)) <= {0, 1}
+    conv = img if cs == "rgb" else oracle.convert_color8(img, cs)
+    if cs != "rgb":
+        eng = get_engine("cuda")
+        assert np.array_equal(eng.convert_color8(eng.to_device(img[None]), cs)[0].cpu().numpy(), conv)
+    wb, *_ = oracle.grabcut(conv, None, n_iter=2, mode=1, rect=(10, 10, 100, 70))
+    assert np.array_equal(m, wb)
+    pipe = GCNGrabCutPipeline(ResGCNNet(hidden_channels=32, n_layers=2).eval(), gc_config=GrabCutConfig(color_space=cs), device="cuda")
+    assert set(np.unique(pipe.segment(img).binary_mask)) <= {0, 1}
 
 
 def test_helper_functions_match_oracle(oracle):
