@@ -74,3 +74,29 @@ def test_pipeline_extras_like_reference():
     assert 0 <= seg_m.iou <= 1 and 0 <= tri_m.trimap_accuracy <= 1
     with pytest.raises(ValueError, match="hidden_channels"):
         GCNTrimapNet(hidden_channels=130, n_layers=2)                                    # wider than the kernels are built for
+
+
+def test_new_entries_fail_loudly_on_bad_arguments(gpu_ctx):
+    """Every C-ABI entry added for the section 8(f) rows reports misuse through its return code (no crash, no silent no-op)."""
+    from gcn_grabcut import _native
+    st = _native.current_stream(0)
+    buf = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    p = buf.data_ptr()
+    bad = [
+        ("ggc_eval_counts", (st, 0, 4, 4, p, p, None, 3, p)),                  # batch 0
+        ("ggc_eval_counts", (st, 1, 4, 4, None, p, None, 3, p)),               # null prediction
+        ("ggc_eval_counts", (st, 1, 4, 4, p, p, None, 1000, p)),               # boundary width out of range
+        ("ggc_region_label_stats", (st, 1, 4, 4, None, p, p, p, p)),           # null segments
+        ("ggc_convert_color8", (st, 16, p, 2, p)),                             # unknown mode
+        ("ggc_convert_color8", (st, 0, p, 0, p)),                              # no pixels
+        ("ggc_gcnnet_configure", (48, 2)),                                     # width the MFMA tiling cannot take
+        ("ggc_gcnnet_configure", (32, 0)),                                     # no layers
+    ]
+    for name, args in bad:
+        with pytest.raises(_native.GGCError):
+            gpu_ctx.call(name, *args)
+    gpu_ctx.call("ggc_gcnnet_configure", 64, 7)                                # a configuration no other test has loaded
+    x = torch.zeros(4, 19, device="cuda")
+    out = torch.zeros(4, 3, device="cuda")
+    with pytest.raises(_native.GGCError, match="missing weight"):
+        gpu_ctx.call("ggc_gcnnet_forward", st, 4, 0, x.data_ptr(), None, None, None, out.data_ptr(), None)   # weights never loaded
