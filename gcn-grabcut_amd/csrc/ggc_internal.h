@@ -15,7 +15,7 @@ constexpr int WAVE = 64;
 
 // Scratch slots: one growing device buffer per slot, owned by the context.
 enum Slot : int {
-    S_CSR_ROWPTR = 0, S_CSR_COL, S_CSR_EID, S_CSR_CURSOR, S_DIS, S_BATCH, S_AGG_PACK, S_EDGE_A, S_EDGE_B,
+    S_CSR_ROWPTR = 0, S_CSR_COL, S_CSR_EID, S_CSR_CURSOR, S_DIS, S_BATCH, S_AGG_PACK,
     S_STATES, S_GATE, S_XW, S_AGG, S_SCORE, S_GVEC, S_HJK,
     S_PRE_A, S_PRE_B, S_PRE_C, S_PRE_D,
     S_SLIC_IMG, S_SLIC_TMP, S_SLIC_CENTERS, S_SLIC_DIST, S_SLIC_LABELS, S_SLIC_AUX,

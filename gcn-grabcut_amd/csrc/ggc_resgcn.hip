@@ -1264,12 +1264,19 @@ int ggc_gcn_aggregate(ggc_ctx* ctx, ggc_stream stream, int N, int D, const float
 //   in_norm -> Linear(19, D) + BatchNorm + ReLU -> n x ResGCNBlock -> head on the concatenated block outputs
 //   ResGCNBlock (:216-232): h' = (relu(bn(GCNConv(h))) + h) * scatter_mean_dst(sigmoid(W2 relu(W1 e + b1) + b2))
 // Reuses the destination CSR, the f32-MFMA product (k_gemm mode 3, no prologue norm) and the GCNConv gather of the
-// ResGCNNet path.  The per-edge gate MLP is two products over the E x D edge matrix: the 5 -> D layer is an
-// element-wise kernel, the D -> D layer is the same MFMA product with E rows, and the scatter-mean is a CSR-ordered
-// sum fused with the block's BatchNorm / ReLU / residual epilogue.  BatchNorm1d(eval) = (x - mean) / sqrt(var + 1e-5)
-// * w + b, like the oracle.
+// ResGCNNet path.  The per-edge gate MLP, its scatter-mean and the block's BatchNorm / ReLU / residual epilogue are one
+// kernel (k_gn_edge_gate, at the end of this file).  BatchNorm1d(eval) = (x - mean) / sqrt(var + 1e-5) * w + b.
 // ===================================================================================================
 namespace ggc {
+
+// destination (row) of every CSR position: row_ptr[r] <= j < row_ptr[r + 1]
+__global__ void __launch_bounds__(256) k_csr_dst(int N, int E, const int32_t* __restrict__ row_ptr, int32_t* __restrict__ csr_dst) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= E) return;
+    int lo = 0, hi = N;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (row_ptr[mid] <= j) lo = mid; else hi = mid; }
+    csr_dst[j] = lo;
+}
 
 struct BnW { const float *w, *b, *rm, *rv; };
 __device__ __forceinline__ float bn_apply(float x, const BnW& p, int k) {
@@ -1299,58 +1306,6 @@ __global__ void __launch_bounds__(256) k_gn_input(int N, const float* __restrict
             }
         }
     }
-}
-
-// first layer of the edge gate MLP: G1[e] = relu(W1 edge_attr[e] + b1), E x D
-template <int D>
-__global__ void __launch_bounds__(256) k_gn_edge1(size_t ED, const float* __restrict__ edge_attr, const float* __restrict__ w1T,
-                                                  const float* __restrict__ b1, float* __restrict__ g1) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ED) return;
-    const size_t e = i / D;
-    const int c = (int)(i % D);
-    const float* a = edge_attr + e * EDGE_CH;
-    float acc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < EDGE_CH; ++k) acc += a[k] * w1T[k * D + c];
-    acc += b1[c];
-    g1[i] = acc > 0.0f ? acc : 0.0f;
-}
-
-// block epilogue: gate = mean over the incoming edges (CSR = edge order) of sigmoid(G2[e] + b2);
-// out = (relu(bn(conv)) + h) * gate.  LPR lanes x float4 per row like the gather kernels.
-template <int D>
-__global__ void __launch_bounds__(256) k_gn_block_out(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ eid,
-                                                      const float* __restrict__ g2, const float* __restrict__ b2,
-                                                      const float* __restrict__ conv, BnW bn, const float* __restrict__ h,
-                                                      float* __restrict__ out) {
-    constexpr int LPR = AggCfg<D>::LPR, RPW = AggCfg<D>::RPW, RPB = AggCfg<D>::RPB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane / LPR, sl = lane % LPR;
-    const int row = blockIdx.x * RPB + wave * RPW + sub;
-    if (row >= N || sl * 4 >= D) return;
-    const int beg = row_ptr[row], end = row_ptr[row + 1];
-    const int c0 = sl * 4;
-    float gs[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j = beg; j < end; ++j) {
-        const float4 v = reinterpret_cast<const float4*>(g2 + (size_t)eid[j] * D)[sl];
-        gs[0] += sigmoid_f(v.x + b2[c0 + 0]); gs[1] += sigmoid_f(v.y + b2[c0 + 1]);
-        gs[2] += sigmoid_f(v.z + b2[c0 + 2]); gs[3] += sigmoid_f(v.w + b2[c0 + 3]);
-    }
-    const int cnt = end - beg;
-    const float c = (float)(cnt > 1 ? cnt : 1);
-    const float4 cv = reinterpret_cast<const float4*>(conv + (size_t)row * D)[sl];
-    const float4 hv = reinterpret_cast<const float4*>(h + (size_t)row * D)[sl];
-    const float cin[4] = {cv.x, cv.y, cv.z, cv.w}, hin[4] = {hv.x, hv.y, hv.z, hv.w};
-    float o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float v = bn_apply(cin[k], bn, c0 + k);
-        v = v > 0.0f ? v : 0.0f;
-        v = v + hin[k];
-        o[k] = v * (gs[k] / c);
-    }
-    reinterpret_cast<float4*>(out + (size_t)row * D)[sl] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // head tail: z = relu(bn(z0 + b0)) -> Linear(D, D/2) + ReLU -> Linear(D/2, 3) (+ softmax); one wave per node
@@ -1470,11 +1425,16 @@ static BnW bn_of(const ResgcnWeights& m, const std::string& prefix) {
 }
 
 template <int D>
+static int launch_edge_gate(ggc_ctx* ctx, hipStream_t st, int N, const int32_t* row_ptr, const int32_t* eid, const int32_t* csr_dst,
+                            const float* edge_attr, const float* w1T, const float* b1, const float* w2p, const float* b2,
+                            const float* conv, const BnW& bn, const float* h, float* out);
+
+template <int D>
 static int forward_gcnnet_t(ggc_ctx* ctx, hipStream_t st, int N, int E, const float* x, const int32_t* edge_src,
                             const int32_t* edge_dst, const float* edge_attr, float* logits, float* probs) {
     ResgcnWeights& m = ctx->model2;
     const int n = m.n_layers, n_states = n + 1;
-    const size_t ND = (size_t)N * D, ED = (size_t)std::max(E, 1) * D;
+    const size_t ND = (size_t)N * D;
     int32_t* row_ptr = scratch_t<int32_t>(ctx, S_CSR_ROWPTR, (size_t)N + 1);
     int32_t* col = scratch_t<int32_t>(ctx, S_CSR_COL, (size_t)std::max(E, 1));
     int32_t* eid = scratch_t<int32_t>(ctx, S_CSR_EID, (size_t)std::max(E, 1));
@@ -1484,11 +1444,15 @@ static int forward_gcnnet_t(ggc_ctx* ctx, hipStream_t st, int N, int E, const fl
     float* xw = scratch_t<float>(ctx, S_XW, ND);
     float* conv = scratch_t<float>(ctx, S_AGG, ND);
     float* z0 = scratch_t<float>(ctx, S_HJK, ND);
-    float* g1 = scratch_t<float>(ctx, S_EDGE_A, ED);
-    float* g2 = scratch_t<float>(ctx, S_EDGE_B, ED);
-    if (!row_ptr || !col || !eid || !cursor || !dis || !states || !xw || !conv || !z0 || !g1 || !g2) return GGC_E_OOM;
+    if (!row_ptr || !col || !eid || !cursor || !dis || !states || !xw || !conv || !z0) return GGC_E_OOM;
     int rc = build_csr(ctx, st, N, E, edge_src, edge_dst, row_ptr, col, eid, cursor, dis);
     if (rc) return rc;
+    int32_t* csr_dst = scratch_t<int32_t>(ctx, S_AGG_PACK, (size_t)std::max(E, 1));        // destination of every CSR position
+    if (!csr_dst) return GGC_E_OOM;
+    if (E > 0) {
+        hipLaunchKernelGGL(k_csr_dst, dim3(cdiv(E, 256)), dim3(256), 0, st, N, E, row_ptr, csr_dst);
+        GGC_LAUNCH_CHECK(ctx);
+    }
     const int wave_blocks = min(cdiv(N, 4), 8 * ctx->n_cu);
     hipLaunchKernelGGL((k_gn_input<D>), dim3(wave_blocks), dim3(256), 0, st, N, x, bn_of(m, "in_norm.norm."),
                        devp(m, "#input_proj.0.weightT"), devp(m, "input_proj.0.bias"), bn_of(m, "input_proj.1."), states);
@@ -1501,17 +1465,11 @@ static int forward_gcnnet_t(ggc_ctx* ctx, hipStream_t st, int N, int E, const fl
         a.A1 = h; a.Wp1 = devp(m, "#" + p + "conv.lin.weight.p"); a.out = xw;
         if ((rc = launch_gemm<D, 3>(ctx, st, N, a))) return rc;
         if ((rc = launch_aggregate<D, 0>(ctx, st, N, xw, row_ptr, col, dis, devp(m, p + "conv.bias"), nullptr, nullptr, conv))) return rc;
-        if (E > 0) {
-            hipLaunchKernelGGL((k_gn_edge1<D>), dim3(cdiv((size_t)E * D, 256)), dim3(256), 0, st, (size_t)E * D, edge_attr,
-                               devp(m, "#" + p + "edge_inject.proj.0.weightT"), devp(m, p + "edge_inject.proj.0.bias"), g1);
-            GGC_LAUNCH_CHECK(ctx);
-            GemmArgs e{};
-            e.A1 = g1; e.Wp1 = devp(m, "#" + p + "edge_inject.proj.2.weight.p"); e.out = g2;
-            if ((rc = launch_gemm<D, 3>(ctx, st, E, e))) return rc;
-        }
-        hipLaunchKernelGGL((k_gn_block_out<D>), dim3(cdiv(N, AggCfg<D>::RPB)), dim3(256), 0, st, N, row_ptr, eid, g2,
-                           devp(m, p + "edge_inject.proj.2.bias"), conv, bn_of(m, p + "bn."), h, out);
-        GGC_LAUNCH_CHECK(ctx);
+        // edge MLP + scatter-mean + block epilogue in one kernel (k_gn_edge_gate below)
+        if ((rc = launch_edge_gate<D>(ctx, st, N, row_ptr, eid, csr_dst, edge_attr, devp(m, "#" + p + "edge_inject.proj.0.weightT"),
+                                      devp(m, p + "edge_inject.proj.0.bias"), devp(m, "#" + p + "edge_inject.proj.2.weight.p"),
+                                      devp(m, p + "edge_inject.proj.2.bias"), conv, bn_of(m, p + "bn."), h, out)))
+            return rc;
     }
     for (int s = 0; s < n_states; ++s) {                       // head.0 on the concatenation = sum of per-state products
         GemmArgs a{};
@@ -1586,3 +1544,180 @@ int ggc_gcnnet_forward(ggc_ctx* ctx, ggc_stream stream, int N, int E, const floa
 }
 
 } // extern "C"
+
+// ===================================================================================================
+// GCNTrimapNet, fused edge gate.  The gate MLP of a block is 316 of the model's 350 GFLOP at batch 256, and done as
+// separate passes its E x D intermediates (2 x 824 MB) cross HBM four times per block.  Here a wave owns a contiguous
+// range of destination nodes — hence a contiguous range of CSR edge positions — and walks it in tiles of 32 edges:
+//   * the first layer relu(W1 e + b1) is generated straight into the MFMA A operand (5 multiply-adds per value);
+//   * the D x D layer runs on v_mfma_f32_32x32x2_f32 against W2 packed in LDS, like k_gemm;
+//   * sigmoid(. + b2) goes through a small LDS tile and is summed per destination in CSR (= edge) order, and at the
+//     end of a destination's edges the block epilogue out = (relu(bn(conv)) + h) * mean is written directly.
+// Nothing of size E x D reaches memory.  Same sums in the same order as the unfused kernels.
+// ===================================================================================================
+namespace ggc {
+
+constexpr int EG_WAVES = 8, EG_NODES = 32;     // waves per block, destination nodes per wave
+constexpr int EG_STAGE = 66;                   // row stride of the sigmoid tile: two 32-column tiles + 2 words of padding
+
+template <int D>
+__global__ void __launch_bounds__(64 * EG_WAVES) k_gn_edge_gate(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ eid,
+                                                                const int32_t* __restrict__ csr_dst,
+                                                                const float* __restrict__ edge_attr, const float* __restrict__ w1T,
+                                                                const float* __restrict__ b1, const float* __restrict__ w2p,
+                                                                const float* __restrict__ b2, const float* __restrict__ conv, BnW bn,
+                                                                const float* __restrict__ h, float* __restrict__ out) {
+    constexpr int T = D / 32, KH = D / 2;
+    extern __shared__ float4 eg_smem4[];                       // W2 packed [D*D] | W1T [5][D] | b1 [D] | per wave stage [32][EG_STAGE]
+    float* s_w1 = reinterpret_cast<float*>(eg_smem4) + (size_t)D * D;
+    float* s_b1 = s_w1 + EDGE_CH * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* stage = s_b1 + D + (size_t)wave * 32 * EG_STAGE;
+    const int hk = lane >> 5, li = lane & 31;
+    for (int i = tid; i < D * D / 4; i += 64 * EG_WAVES) eg_smem4[i] = reinterpret_cast<const float4*>(w2p)[i];
+    for (int i = tid; i < EDGE_CH * D; i += 64 * EG_WAVES) s_w1[i] = w1T[i];
+    for (int i = tid; i < D; i += 64 * EG_WAVES) s_b1[i] = b1[i];
+    __syncthreads();
+    const int n0 = (blockIdx.x * EG_WAVES + wave) * EG_NODES;
+    if (n0 >= N) return;                                        // (after the only block barrier)
+    const int n1 = min(n0 + EG_NODES, N);
+    const int e0 = row_ptr[n0], e1 = row_ptr[n1];
+
+    // epilogue of one destination for this lane's column of column tile t
+    auto flush = [&](int node, int t, float sum) {
+        const int c = 32 * t + li;
+        const int cnt = row_ptr[node + 1] - row_ptr[node];
+        const float cf = (float)(cnt > 1 ? cnt : 1);
+        float v = bn_apply(conv[(size_t)node * D + c], bn, c);
+        v = v > 0.0f ? v : 0.0f;
+        v = v + h[(size_t)node * D + c];
+        out[(size_t)node * D + c] = v * (sum / cf);
+    };
+    float sums[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) sums[t] = 0.0f;
+    int cur = n0;                                               // destination whose edges are being summed (wave-uniform)
+    // the tile's inputs (edge attributes through eid, destination of every CSR position) are dependent global loads: the
+    // next tile's are fetched while this tile's MFMAs run
+    float ea_n[EDGE_CH] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int dnode_n = n1;
+    auto fetch = [&](int base) {
+        const int j = base + li;
+#pragma unroll
+        for (int k = 0; k < EDGE_CH; ++k) ea_n[k] = 0.0f;
+        dnode_n = n1;
+        if (j < e1) {
+            const float* a = edge_attr + (size_t)eid[j] * EDGE_CH;
+#pragma unroll
+            for (int k = 0; k < EDGE_CH; ++k) ea_n[k] = a[k];
+            dnode_n = csr_dst[j];
+        }
+    };
+    fetch(e0);
+    for (int base = e0; base < e1; base += 32) {
+        // ---- A operand: this lane's half row of relu(W1 e + b1) for edge position base + li
+        const bool have = base + li < e1;
+        float ea[EDGE_CH];
+#pragma unroll
+        for (int k = 0; k < EDGE_CH; ++k) ea[k] = ea_n[k];
+        const int dnode = dnode_n;
+        if (base + 32 < e1) fetch(base + 32);
+        float a[KH];
+#pragma unroll
+        for (int s = 0; s < KH; s += 4) {                       // four values at a time on the packed-f32 pipe, same op order
+            const int c = hk * KH + s;
+            v4f acc4 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < EDGE_CH; ++k) acc4 += ea[k] * *reinterpret_cast<const v4f*>(s_w1 + k * D + c);
+            acc4 += *reinterpret_cast<const v4f*>(s_b1 + c);
+            a[s + 0] = (have && acc4.x > 0.0f) ? acc4.x : 0.0f; a[s + 1] = (have && acc4.y > 0.0f) ? acc4.y : 0.0f;
+            a[s + 2] = (have && acc4.z > 0.0f) ? acc4.z : 0.0f; a[s + 3] = (have && acc4.w > 0.0f) ? acc4.w : 0.0f;
+        }
+        f32x16 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+        for (int s4 = 0; s4 < KH / 4; ++s4) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float4 b = eg_smem4[(s4 * T + t) * 64 + lane];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 0], b.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 1], b.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 2], b.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 3], b.w, acc[t], 0, 0, 0);
+            }
+        }
+        const int n_rows = min(32, e1 - base);
+        const int cur_in = cur;
+        // ---- two column tiles at a time: sigmoid through the LDS tile, then an ordered walk down the rows in which lane
+        // (hk, li) owns column 32 (t + hk) + li
+        int c_last = cur_in;
+#pragma unroll
+        for (int t = 0; t < T; t += 2) {
+#pragma unroll
+            for (int tt = 0; tt < 2 && t + tt < T; ++tt) {
+                const float bias = b2[32 * (t + tt) + li];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // sigmoid on the transcendental unit: 1 / (1 + 2^(-x log2 e)), ~1e-7 relative
+                    const float z = acc[t + tt][r] + bias;
+                    stage[((r & 3) + 8 * (r >> 2) + 4 * hk) * EG_STAGE + 32 * tt + li] =
+                        __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int mt = t + hk;                              // this lane's column tile in the walk
+            const bool mine = mt < T;
+            float sum = 0.0f;
+#pragma unroll
+            for (int q = 0; q < T; ++q) if (q == mt) sum = sums[q];
+            int c_node = cur_in;
+            for (int row = 0; row < n_rows; ++row) {
+                const int nd = __shfl(dnode, row, 64);          // wave-uniform
+                if (nd != c_node) {
+                    if (mine) {
+                        flush(c_node, mt, sum);
+                        for (int z = c_node + 1; z < nd; ++z) flush(z, mt, 0.0f);     // destinations without edges
+                    }
+                    c_node = nd; sum = 0.0f;
+                }
+                sum += stage[row * EG_STAGE + 32 * hk + li];
+            }
+#pragma unroll
+            for (int q = 0; q < T; ++q) if (q == mt) sums[q] = sum;
+            c_last = c_node;
+            __builtin_amdgcn_wave_barrier();
+        }
+        cur = c_last;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if ((t & 1) == hk) {                                    // the lane half that summed this column tile
+            flush(cur, t, sums[t]);
+            for (int z = cur + 1; z < n1; ++z) flush(z, t, 0.0f);
+        }
+    }
+}
+
+template <int D>
+static int launch_edge_gate(ggc_ctx* ctx, hipStream_t st, int N, const int32_t* row_ptr, const int32_t* eid, const int32_t* csr_dst,
+                            const float* edge_attr, const float* w1T, const float* b1, const float* w2p, const float* b2,
+                            const float* conv, const BnW& bn, const float* h, float* out) {
+    const size_t lds = ((size_t)D * D + (size_t)EDGE_CH * D + D + (size_t)EG_WAVES * 32 * EG_STAGE) * sizeof(float);
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
+        GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gn_edge_gate<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+        attr_set.store(true, std::memory_order_release);
+    }
+    ProfScope prof(ctx, st, "gcnnet_edge_gate");
+    hipLaunchKernelGGL((k_gn_edge_gate<D>), dim3(cdiv(N, EG_WAVES * EG_NODES)), dim3(64 * EG_WAVES), lds, st, N, row_ptr, eid, csr_dst,
+                       edge_attr, w1T, b1, w2p, b2, conv, bn, h, out);
+    GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
+
+} // namespace ggc
