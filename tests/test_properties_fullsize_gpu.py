@@ -1,0 +1,81 @@
+"""Size-independent properties at BASELINE.json's full configuration (configs[2]: batch 256 of 400x300, 600 superpixels),
+where the oracle is too slow to check every image: determinism, independence of an image's result from its batch
+neighbours, structural invariants of every stage.  (Per-image oracle parity at this size is sampled by bench.py.)"""
+import numpy as np
+import pytest
+import torch
+from scipy import ndimage
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_run():
+    from gcn_grabcut import GCNGrabCutPipeline, ResGCNNet, SuperpixelGraphConfig
+    from gcn_grabcut.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    pipe = GCNGrabCutPipeline(ResGCNNet(hidden_channels=128, n_layers=6).eval(), sp_config=SuperpixelGraphConfig(n_segments=600),
+                              device="cuda")
+    imgs = synthetic_batch(256, 300, 400, config_id=3)
+    bgr = torch.from_numpy(imgs).cuda()
+    out = pipe.segment_batch_device(bgr)
+    torch.cuda.synchronize()
+    return pipe, imgs, bgr, out
+
+
+def test_two_runs_are_identical(full_run):
+    pipe, imgs, bgr, out = full_run
+    again = pipe.segment_batch_device(bgr)
+    for k in ("segments", "trimap", "gc_mask", "binary_mask", "probs", "overlay", "rgba"):
+        assert torch.equal(out[k], again[k]), k                      # no atomics-order or lane-schedule dependence anywhere
+    assert torch.equal(out["graphs"].edge_src, again["graphs"].edge_src) and torch.equal(out["graphs"].x, again["graphs"].x)
+
+
+def test_an_image_does_not_depend_on_its_batch_neighbours(full_run):
+    pipe, imgs, bgr, out = full_run
+    pick = [200, 3, 77, 255, 128, 31, 64, 9]
+    sub = pipe.segment_batch_device(bgr[pick].contiguous())
+    g, gs = out["graphs"], sub["graphs"]
+    for j, i in enumerate(pick):
+        assert torch.equal(sub["segments"][j], out["segments"][i])
+        n0, n1, m0, m1 = int(g.node_ptr_host[i]), int(g.node_ptr_host[i + 1]), int(gs.node_ptr_host[j]), int(gs.node_ptr_host[j + 1])
+        assert n1 - n0 == m1 - m0 and torch.equal(gs.x[m0:m1], g.x[n0:n1])
+        e0, e1, f0, f1 = int(g.edge_ptr_host[i]), int(g.edge_ptr_host[i + 1]), int(gs.edge_ptr_host[j]), int(gs.edge_ptr_host[j + 1])
+        assert torch.equal(gs.edge_src[f0:f1] - m0, g.edge_src[e0:e1] - n0) and torch.equal(gs.edge_attr[f0:f1], g.edge_attr[e0:e1])
+        # the GCN treats graphs independently (per-graph readout): same probabilities up to summation noise, same trimap
+        assert (sub["probs"][m0:m1] - out["probs"][n0:n1]).abs().max().item() <= 1e-5
+        assert (sub["trimap"][j] == out["trimap"][i]).float().mean().item() >= 0.9999
+    # (GrabCut seeds its k-means++ with seed + position in the batch, like consecutive calls of a global RNG: masks are
+    #  compared per position by test_two_runs_are_identical, not across positions)
+
+
+def test_structural_invariants_of_every_stage(full_run):
+    pipe, imgs, bgr, out = full_run
+    g = out["graphs"]
+    seg = out["segments"].cpu().numpy()
+    n_nodes = np.diff(g.node_ptr_host)
+    assert (n_nodes > 400).all() and (n_nodes < 700).all()
+    src, dst = g.edge_src.cpu().numpy(), g.edge_dst.cpu().numpy()
+    for i in (0, 100, 255):
+        n0, n1, e0, e1 = int(g.node_ptr_host[i]), int(g.node_ptr_host[i + 1]), int(g.edge_ptr_host[i]), int(g.edge_ptr_host[i + 1])
+        s = seg[i]
+        assert s.min() == 0 and s.max() == n1 - n0 - 1 and len(np.unique(s)) == n1 - n0        # labels are 0..N-1, all used
+        for lab in (0, (n1 - n0) // 2, n1 - n0 - 1):                                           # enforce_connectivity: one 4-connected piece
+            assert ndimage.label(s == lab)[1] == 1
+        a, b = src[e0:e1] - n0, dst[e0:e1] - n0
+        assert a.min() >= 0 and a.max() < n1 - n0 and b.min() >= 0 and b.max() < n1 - n0 and (a != b).all()
+        half = (e1 - e0) // 2
+        assert (e1 - e0) % 2 == 0 and np.array_equal(a[:half], b[half:]) and np.array_equal(b[:half], a[half:])   # mirrored copy
+        assert (a[:half] < b[:half]).all()                                                     # canonical (lo, hi) pairs
+    probs = out["probs"]
+    assert torch.isfinite(probs).all() and (probs.sum(1) - 1).abs().max().item() <= 1e-5
+    tri, gcm, binm = out["trimap"], out["gc_mask"], out["binary_mask"]
+    assert int(tri.max()) <= 3 and int(gcm.max()) <= 3 and int(binm.max()) <= 1
+    definite_bg, definite_fg = tri == 0, tri == 1
+    assert torch.equal(gcm[definite_bg], tri[definite_bg]) and torch.equal(gcm[definite_fg], tri[definite_fg])   # GrabCut never moves definite pixels
+    cleaned_again = pipe._eng.clean_mask(binm, 0.002, False)
+    assert torch.equal(cleaned_again, binm)                                                    # clean_mask is idempotent
+    assert (binm.bool() & ~((gcm == 1) | (gcm == 3))).sum().item() == 0                        # the clean mask only removes foreground
+    ov, rgba = out["overlay"], out["rgba"]
+    assert torch.equal(rgba[..., :3], bgr) and torch.equal(rgba[..., 3], binm * 255)
+    assert torch.equal(ov[binm == 0], bgr[binm == 0])
