@@ -102,7 +102,7 @@ def main() -> None:
     ap.add_argument("--workload", choices=["full", "gcn"], default="full")
     ap.add_argument("--lanes", type=int, default=4, help="concurrent sub-batches of the GrabCut stage (full workload)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default 256 full / 64 gcn)")
-    ap.add_argument("--cpu-sample", type=int, default=6, help="images timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=40, help="images timed on the CPU oracle, ~12 s of one core (0 = skip)")
     args = ap.parse_args()
     batch_size = args.batch or (256 if args.workload == "full" else 64)
 
