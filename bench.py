@@ -97,8 +97,8 @@ def pmc_traffic(workload: str, batch: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["full", "gcn"], default="full")
     ap.add_argument("--lanes", type=int, default=4, help="concurrent sub-batches of the GrabCut stage (full workload)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default 256 full / 64 gcn)")

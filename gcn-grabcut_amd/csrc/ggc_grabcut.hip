@@ -189,43 +189,91 @@ __global__ void __launch_bounds__(256) k_km_chunks(GcDims d, int k, const uint8_
     }
 }
 
-// One thread per (image, class): draw the k-th centre exactly like the oracle.
-__global__ void k_km_pick(GcDims d, int k, uint64_t seed, const uint8_t* __restrict__ img,
-                          const uint8_t* __restrict__ mask, const int32_t* __restrict__ state,
-                          const int32_t* __restrict__ d2, const int64_t* __restrict__ chunk_cnt,
-                          const int64_t* __restrict__ chunk_d2, KmState* __restrict__ km) {
-    const int b = blockIdx.x, c = threadIdx.x;
-    if (c >= 2 || state[b]) return;
+__device__ __forceinline__ long long wave_sum64(long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ long long wave_scan64(long long v, int lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// One wave per (image, class): draw the k-th centre exactly like the oracle's serial walk (first pixel of the class
+// whose running count / D^2 sum exceeds the drawn threshold), as prefix scans over 64 chunks / 64 pixels at a time.
+__global__ void __launch_bounds__(128) k_km_pick(GcDims d, int k, uint64_t seed, const uint8_t* __restrict__ img,
+                                                 const uint8_t* __restrict__ mask, const int32_t* __restrict__ state,
+                                                 const int32_t* __restrict__ d2, const int64_t* __restrict__ chunk_cnt,
+                                                 const int64_t* __restrict__ chunk_d2, KmState* __restrict__ km) {
+    const int b = blockIdx.x, c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (state[b]) return;
     KmState& s = km[b * 2 + c];
     const int64_t* cc = chunk_cnt + ((size_t)b * 2 + c) * d.n_chunks;
     const int64_t* cd = chunk_d2 + ((size_t)b * 2 + c) * d.n_chunks;
+    long long n; int K; uint64_t rng;
     if (k == 0) {
-        int64_t n = 0;
-        for (int i = 0; i < d.n_chunks; ++i) n += cc[i];
-        s.n = n; s.K = n < NCOMP ? (int)n : NCOMP;
-        s.rng = (seed + (uint64_t)b) * 2 + (uint64_t)c + 1;
+        long long part = 0;
+        for (int i = lane; i < d.n_chunks; i += 64) part += cc[i];
+        n = wave_sum64(part);
+        K = n < NCOMP ? (int)n : NCOMP;
+        rng = (seed + (uint64_t)b) * 2 + (uint64_t)c + 1;
+        if (lane == 0) { s.n = n; s.K = K; s.rng = rng; }
+    } else { n = s.n; K = s.K; rng = s.rng; }
+    if (k >= K) return;
+    long long total = 0;
+    if (k > 0) {
+        long long part = 0;
+        for (int i = lane; i < d.n_chunks; i += 64) part += cd[i];
+        total = wave_sum64(part);
     }
-    if (k >= s.K) return;
-    int64_t total = 0;
-    if (k > 0) for (int i = 0; i < d.n_chunks; ++i) total += cd[i];
-    const uint64_t r = splitmix(s.rng);
+    const uint64_t r = splitmix(rng);
     const bool by_d2 = k > 0 && total > 0;
-    const int64_t t = by_d2 ? (int64_t)(r % (uint64_t)total) : (int64_t)(r % (uint64_t)s.n);
+    const long long t = by_d2 ? (long long)(r % (uint64_t)total) : (long long)(r % (uint64_t)n);
     const int64_t* w = by_d2 ? cd : cc;
-    int64_t run = 0;
-    int ch = 0;
-    for (; ch < d.n_chunks - 1; ++ch) { if (run + w[ch] > t) break; run += w[ch]; }
+    // chunk holding the threshold (the last chunk when no prefix exceeds it)
+    long long run = 0;
+    int ch = d.n_chunks - 1;
+    for (int base = 0; base < d.n_chunks; base += 64) {
+        const int i = base + lane;
+        const long long v = i < d.n_chunks ? (long long)w[i] : 0;
+        const long long incl = wave_scan64(v, lane);
+        const unsigned long long hit = __ballot(i < d.n_chunks && run + incl > t);
+        if (hit) {
+            const int l = __ffsll((long long)hit) - 1;
+            ch = base + l;
+            run += __shfl(incl - v, l, 64);
+            break;
+        }
+        run += __shfl(incl, 63, 64);
+    }
+    if (ch == d.n_chunks - 1) {                 // also the fallback: everything before the last chunk
+        long long part = 0;
+        for (int i = lane; i < d.n_chunks - 1; i += 64) part += w[i];
+        run = wave_sum64(part);
+    }
     int pick = -1, last = -1;
     const int p_end = min((ch + 1) * CHUNK, d.P);
-    for (int p = ch * CHUNK; p < p_end; ++p) {
-        if ((is_bg(mask[(size_t)b * d.P + p]) ? 0 : 1) != c) continue;
-        last = p;
-        run += by_d2 ? (int64_t)d2[(size_t)b * d.P + p] : 1;
-        if (run > t) { pick = p; break; }
+    for (int base = ch * CHUNK; base < p_end; base += 64) {
+        const int p = base + lane;
+        const bool mine = p < p_end && (is_bg(mask[(size_t)b * d.P + p]) ? 0 : 1) == c;
+        const long long v = mine ? (by_d2 ? (long long)d2[(size_t)b * d.P + p] : 1) : 0;
+        const long long incl = wave_scan64(v, lane);
+        const unsigned long long any = __ballot(mine);
+        if (any) last = base + 63 - __clzll((long long)any);
+        const unsigned long long hit = __ballot(mine && run + incl > t);
+        if (hit) { pick = base + __ffsll((long long)hit) - 1; break; }
+        run += __shfl(incl, 63, 64);
     }
     if (pick < 0) pick = last;                  // cannot happen for consistent sums; keeps the kernel total
-    s.cen_px[k] = pick;
-    for (int ch3 = 0; ch3 < 3; ++ch3) s.cen[k][ch3] = (double)img[((size_t)b * d.P + pick) * 3 + ch3];
+    if (lane == 0) {
+        s.rng = rng;
+        s.cen_px[k] = pick;
+        for (int ch3 = 0; ch3 < 3; ++ch3) s.cen[k][ch3] = (double)img[((size_t)b * d.P + pick) * 3 + ch3];
+    }
 }
 
 // accumulators per (image, class, component): count, 3 sums, 9 products (int64, exact)
@@ -556,7 +604,7 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
         int64_t* chunk_d2 = chunks + (size_t)B * 2 * d.n_chunks;
         for (int k = 0; k < NCOMP; ++k) {
             hipLaunchKernelGGL(k_km_chunks, dim3(d.n_chunks, B), dim3(256), 0, st, d, k, image, mask, state, km, d2, chunk_cnt, chunk_d2);
-            hipLaunchKernelGGL(k_km_pick, dim3(B), dim3(64), 0, st, d, k, (uint64_t)seed, image, mask, state, d2, chunk_cnt, chunk_d2, km);
+            hipLaunchKernelGGL(k_km_pick, dim3(B), dim3(128), 0, st, d, k, (uint64_t)seed, image, mask, state, d2, chunk_cnt, chunk_d2, km);
         }
         for (int it = 0; it < 10; ++it) {
             hipLaunchKernelGGL(k_km_assign, dim3(cdiv(d.P, 256 * BIN_PX), B), dim3(256), 0, st, d, image, mask, state, km, comp, acc);

@@ -390,8 +390,11 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             // few active pixels: their labels stay exact, so more (cheap) launches beat another global relabel
             // first round: labels go stale fastest while most excess is still moving, an early relabel pays (12 vs 24: +3 %)
             const int launches = total_active <= tail_active ? tail_launch : (round == 0 ? n_launch0 : n_launch);
+            // an active pixel opens at most its own tile: empty blocks only add dispatch time to launches that are pure latency
+            static const int grid_per_active = env_int("GGC_MF_GRID_PER_ACTIVE", 2);
+            const int grid = (int)std::min<long long>(pr_grid, std::max<long long>(128, (long long)total_active * grid_per_active));
             for (int phase = 0; phase < launches; ++phase)
-                hipLaunchKernelGGL(k_mf_pr_list, dim3(pr_grid), dim3(PT_N), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
+                hipLaunchKernelGGL(k_mf_pr_list, dim3(grid), dim3(PT_N), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
                                    pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
             GGC_LAUNCH_CHECK(ctx);
             if (trace) {
