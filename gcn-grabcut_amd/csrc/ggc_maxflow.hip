@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
                                                        const int32_t* __restrict__ list_in, int32_t* __restrict__ list_out,
                                                        int32_t* __restrict__ flag_in, int32_t* __restrict__ flag_out) {
     __shared__ int sd[RT + 2][RT + 2];
+    __shared__ int s_nb;
     const int tid = threadIdx.x;
     const int n_in = counters[phase % 3];
     int32_t* n_out = counters + (phase + 1) % 3;
@@ -94,6 +95,7 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
         const int tx0 = txi * RT, ty0 = tyi * RT;
         const size_t base = (size_t)b * d.P;
         __syncthreads();                                                   // previous tile's LDS use is over
+        if (tid == 0) s_nb = 0;
         for (int i = tid; i < (RT + 2) * (RT + 2); i += 256) {
             const int ly = i / (RT + 2), llx = i % (RT + 2);
             const int gy = ty0 + ly - 1, gx = tx0 + llx - 1;
@@ -110,6 +112,7 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
         if (tid == 0) flag_in[tile] = 0;                                   // consumed
 #pragma unroll
         for (int j = 0; j < RT_NJ; ++j) old[j] = sd[(tid / RT) + RT_ROWS * j + 1][lx + 1];
+        bool settled = false;
         for (int it = 0; it < 4 * RT; ++it) {
             int ch = 0;
 #pragma unroll
@@ -127,16 +130,24 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
                 if (msk[j] & 128) nd = min(nd, sd[ly + 1][cx - 1]);
                 if (nd < DINF && nd + 1 < sd[ly][cx]) { sd[ly][cx] = nd + 1; ch = 1; }
             }
-            if (!__syncthreads_or(ch)) break;
+            if (!__syncthreads_or(ch)) { settled = true; break; }
         }
-        int any = 0;
+        // A neighbour tile only has to go again when a pixel of its halo changed, i.e. a pixel on our border towards
+        // it (3 of 4 tile visits used to find nothing new); this tile itself only when the sweep cap cut it short.
+        int nbm = settled ? 0 : 1 << 4;                                    // bit (dy + 1) * 3 + (dx + 1)
 #pragma unroll
         for (int j = 0; j < RT_NJ; ++j) {
             const int ly = (tid / RT) + RT_ROWS * j;
             const int v = sd[ly + 1][lx + 1];
-            if (v != old[j]) { dist[base + (size_t)(ty0 + ly) * d.W + tx0 + lx] = v; any = 1; }
+            if (v != old[j]) {
+                dist[base + (size_t)(ty0 + ly) * d.W + tx0 + lx] = v;
+                const int L = lx == 0, R = lx == RT - 1, U = ly == 0, D = ly == RT - 1;
+                nbm |= (U & L) | U << 1 | (U & R) << 2 | L << 3 | R << 5 | (D & L) << 6 | D << 7 | (D & R) << 8;
+            }
         }
-        if (__syncthreads_or(any) && tid < 9) {                            // changed: this tile and its 8 neighbours go again
+        if (nbm) atomicOr(&s_nb, nbm);
+        __syncthreads();
+        if (tid < 9 && (s_nb >> tid) & 1) {
             const int ty = tyi + tid / 3 - 1, tx = txi + tid % 3 - 1;
             if (ty >= 0 && ty < tl.rt_y && tx >= 0 && tx < tl.rt_x)
                 push_tile(b * tiles_per_image + ty * tl.rt_x + tx, flag_out, list_out, n_out);
