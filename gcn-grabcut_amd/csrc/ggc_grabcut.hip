@@ -357,9 +357,12 @@ __global__ void __launch_bounds__(256) k_gmm_accum(GcDims d, const uint8_t* __re
             const size_t gp = (size_t)b * d.P + p;
             const int c = is_bg(mask[gp]) ? 0 : 1;
             const uint8_t* px = img + gp * 3;
-            int ci;
-            if (MODE == 1) { ci = gmm_which(gmm[b * 2 + c], px); comp[gp] = (uint8_t)ci; }
-            else ci = comp[gp];
+            int ci = 0;
+            if (MODE == 1) {   // class by class: the GMM address stays wave-uniform (scalar loads), waves are mostly one class
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) if (c == cc) ci = gmm_which(gmm[b * 2 + cc], px);
+                comp[gp] = (uint8_t)ci;
+            } else ci = comp[gp];
             unsigned int* a = s_acc + (c * NCOMP + ci) * LW * BIN_COPIES + cp;
             const unsigned int v0 = px[0], v1 = px[1], v2 = px[2];
             atomicAdd(&a[0], 1u);
@@ -484,11 +487,11 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
                                                      const Gmm* __restrict__ gmm, const int32_t* __restrict__ nw,
                                                      int32_t* __restrict__ rc, int32_t* __restrict__ ex,
                                                      int32_t* __restrict__ snk, int warm) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one image per grid row: the image index is uniform, so the two GMMs (140 doubles) come through scalar loads
+    const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t BP = (size_t)d.B * d.P;
-    if (i >= BP) return;
-    const int b = (int)(i / d.P), p = (int)(i % d.P);
-    if (state[b]) return;
+    if (p >= d.P || state[b]) return;
+    const size_t i = (size_t)b * d.P + p;
     const int y = p / d.W, x = p % d.W;
     const uint8_t m = mask[i];
     double dv;
@@ -625,7 +628,7 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                 hipLaunchKernelGGL((k_gmm_accum<1>), dim3(cdiv(d.P, 256 * BIN_PX), B), dim3(256), 0, st, d, image, mask, state, gmm, comp, acc);
                 hipLaunchKernelGGL(k_gmm_learn, dim3(cdiv(B * 2, 64)), dim3(64), 0, st, B, state, acc, gmm);
                 static const bool warm_ok = [] { const char* e = std::getenv("GGC_MF_WARM"); return !(e && e[0] == '0'); }();
-                hipLaunchKernelGGL(k_build_graph, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk,
+                hipLaunchKernelGGL(k_build_graph, dim3(cdiv(d.P, 256), B), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk,
                                    (warm_ok && it > 0) ? 1 : 0);
             }
             GGC_LAUNCH_CHECK(ctx);
