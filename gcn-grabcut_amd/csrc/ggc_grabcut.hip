@@ -300,13 +300,17 @@ __global__ void __launch_bounds__(256) k_km_assign(GcDims d, const uint8_t* __re
         if (p < d.P) {
             const size_t gp = (size_t)b * d.P + p;
             const int c = is_bg(mask[gp]) ? 0 : 1;
-            const KmState& s = km[b * 2 + c];
             const uint8_t* px = img + gp * 3;
             int best = 0; double bd = 0.0;
-            for (int k = 0; k < s.K; ++k) {
-                const double a0 = (double)px[0] - s.cen[k][0], a1 = (double)px[1] - s.cen[k][1], a2 = (double)px[2] - s.cen[k][2];
-                const double dist = (a0 * a0 + a1 * a1) + a2 * a2;
-                if (k == 0 || dist < bd) { best = k; bd = dist; }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {                               // class by class: centres through scalar loads
+                if (c != cc) continue;
+                const KmState& s = km[b * 2 + cc];
+                for (int k = 0; k < s.K; ++k) {
+                    const double a0 = (double)px[0] - s.cen[k][0], a1 = (double)px[1] - s.cen[k][1], a2 = (double)px[2] - s.cen[k][2];
+                    const double dist = (a0 * a0 + a1 * a1) + a2 * a2;
+                    if (k == 0 || dist < bd) { best = k; bd = dist; }
+                }
             }
             comp[gp] = (uint8_t)best;
             unsigned int* a = s_acc + (c * NCOMP + best) * 4 * BIN_COPIES + cp;
