@@ -96,17 +96,25 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
         const size_t base = (size_t)b * d.P;
         __syncthreads();                                                   // previous tile's LDS use is over
         if (tid == 0) s_nb = 0;
-        for (int i = tid; i < (RT + 2) * (RT + 2); i += 256) {
-            const int ly = i / (RT + 2), llx = i % (RT + 2);
-            const int gy = ty0 + ly - 1, gx = tx0 + llx - 1;
-            sd[ly][llx] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
+        // every global load of the visit is issued before the first LDS store waits for one
+        constexpr int N_HALO = (RT + 2) * (RT + 2), HALO_IT = (N_HALO + 255) / 256;
+        int hv[HALO_IT], msk[RT_NJ], old[RT_NJ];
+#pragma unroll
+        for (int k = 0; k < HALO_IT; ++k) {
+            const int i = tid + k * 256;
+            const int gy = ty0 + i / (RT + 2) - 1, gx = tx0 + i % (RT + 2) - 1;
+            hv[k] = (i < N_HALO && gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
         }
-        int msk[RT_NJ], old[RT_NJ];
 #pragma unroll
         for (int j = 0; j < RT_NJ; ++j) {
             const int ly = (tid / RT) + RT_ROWS * j;
             const int gy = ty0 + ly, gx = tx0 + lx;
             msk[j] = (gx < d.W && gy < d.H) ? rmask[base + (size_t)gy * d.W + gx] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < HALO_IT; ++k) {
+            const int i = tid + k * 256;
+            if (i < N_HALO) sd[i / (RT + 2)][i % (RT + 2)] = hv[k];
         }
         __syncthreads();
         if (tid == 0) flag_in[tile] = 0;                                   // consumed
@@ -155,17 +163,21 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
     }
 }
 
-// Push-relabel sweeps over a work list of 32x8 tiles.
-__global__ void __launch_bounds__(PT_N) k_mf_pr_list(GcDims d, MfTiles tl, int phase, int inner,
-                                                    int32_t* __restrict__ rc, int32_t* __restrict__ ex,
-                                                    int32_t* __restrict__ snk, int32_t* __restrict__ dist,
-                                                    int32_t* __restrict__ counters, const int32_t* __restrict__ list_in,
-                                                    int32_t* __restrict__ list_out, int32_t* __restrict__ flag_in,
-                                                    int32_t* __restrict__ flag_out) {
+// Push-relabel sweeps over a work list of 32x8 tiles.  PPT pixels per thread: a dense launch is bound by tile visits in
+// flight per CU (visit latency ~9 us x the blocks a CU holds), and a CU holds 32 waves whatever the block size, so
+// PPT = 2 (two waves per tile) doubles the tiles in flight.
+template <int PPT>
+__global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl, int phase, int inner,
+                                                          int32_t* __restrict__ rc, int32_t* __restrict__ ex,
+                                                          int32_t* __restrict__ snk, int32_t* __restrict__ dist,
+                                                          int32_t* __restrict__ counters, const int32_t* __restrict__ list_in,
+                                                          int32_t* __restrict__ list_out, int32_t* __restrict__ flag_in,
+                                                          int32_t* __restrict__ flag_out) {
+    constexpr int NT = PT_N / PPT;                                         // threads; pixel slot of (thread, j) = tid + j * NT
     __shared__ int s_ex[PT_N];
     __shared__ int s_d[PT_H + 2][PT_W + 2];
     __shared__ int s_rc[8][PT_N];
-    const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
+    const int tid = threadIdx.x, lx = tid & 31;
     const int n_in = counters[phase % 3];
     int32_t* n_out = counters + (phase + 1) % 3;
     if (blockIdx.x == 0 && tid == 0) counters[(phase + 2) % 3] = 0;
@@ -175,49 +187,74 @@ __global__ void __launch_bounds__(PT_N) k_mf_pr_list(GcDims d, MfTiles tl, int p
         const int tile = list_in[t];
         const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
         const int tyi = tr / tl.pt_x, txi = tr % tl.pt_x;
-        const int x = txi * PT_W + lx, y = tyi * PT_H + ly;
-        const bool inb = x < d.W && y < d.H;
+        const int x = txi * PT_W + lx;
         const size_t base = (size_t)b * d.P;
-        const int p = y * d.W + x;
         __syncthreads();
-        int e0 = 0, sk0 = 0, r0[8];
-        if (inb) { e0 = ex[base + p]; sk0 = snk[base + p]; }
-        s_ex[tid] = e0;
+        int e0[PPT], sk0[PPT], sk[PPT], d0[PPT], r0[PPT][8], pp[PPT];
+        bool inb[PPT];
 #pragma unroll
-        for (int dir = 0; dir < 8; ++dir) { r0[dir] = inb ? rc[(size_t)dir * BP + base + p] : 0; s_rc[dir][tid] = r0[dir]; }
-        for (int i = tid; i < (PT_H + 2) * (PT_W + 2); i += PT_N) {
+        for (int j = 0; j < PPT; ++j) {
+            const int slot = tid + j * NT, y = tyi * PT_H + (slot >> 5);
+            inb[j] = x < d.W && y < d.H;
+            pp[j] = y * d.W + x;
+            e0[j] = 0; sk0[j] = 0;
+            if (inb[j]) { e0[j] = ex[base + pp[j]]; sk0[j] = snk[base + pp[j]]; }
+#pragma unroll
+            for (int dir = 0; dir < 8; ++dir) r0[j][dir] = inb[j] ? rc[(size_t)dir * BP + base + pp[j]] : 0;
+        }
+        // every global load of the visit is issued before the first LDS store waits for one
+        constexpr int N_HALO = (PT_H + 2) * (PT_W + 2), HALO_IT = (N_HALO + NT - 1) / NT;
+        int hv[HALO_IT];
+#pragma unroll
+        for (int k = 0; k < HALO_IT; ++k) {
+            const int i = tid + k * NT;
             const int gy = tyi * PT_H + i / (PT_W + 2) - 1, gx = txi * PT_W + i % (PT_W + 2) - 1;
-            s_d[i / (PT_W + 2)][i % (PT_W + 2)] =
-                (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
+            hv[k] = (i < N_HALO && gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int slot = tid + j * NT;
+            s_ex[slot] = e0[j];
+            sk[j] = sk0[j];
+#pragma unroll
+            for (int dir = 0; dir < 8; ++dir) s_rc[dir][slot] = r0[j][dir];
+        }
+#pragma unroll
+        for (int k = 0; k < HALO_IT; ++k) {
+            const int i = tid + k * NT;
+            if (i < N_HALO) s_d[i / (PT_W + 2)][i % (PT_W + 2)] = hv[k];
         }
         __syncthreads();
         if (tid == 0) flag_in[tile] = 0;                                   // consumed
-        const int d0 = s_d[ly + 1][lx + 1];
-        int sk = sk0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) d0[j] = s_d[((tid + j * NT) >> 5) + 1][lx + 1];
         for (int it = 0; it < inner; ++it) {
             int act = 0;
-            if (inb) {
-                const int e = __hip_atomic_load(&s_ex[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                if (!inb[j]) continue;
+                const int slot = tid + j * NT, ly = slot >> 5;
+                const int e = __hip_atomic_load(&s_ex[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int dp = s_d[ly + 1][lx + 1];
                 if (e > 0 && dp < d.P) {
                     act = 1;
                     int hmin = DINF, best = -1;
-                    if (sk > 0) { hmin = 0; best = 8; }
+                    if (sk[j] > 0) { hmin = 0; best = 8; }
 #pragma unroll
                     for (int dir = 0; dir < 8; ++dir)
-                        if (__hip_atomic_load(&s_rc[dir][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) {
+                        if (__hip_atomic_load(&s_rc[dir][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) {
                             const int hq = s_d[ly + 1 + dir_dy(dir)][lx + 1 + dir_dx(dir)];
                             if (hq < hmin) { hmin = hq; best = dir; }
                         }
                     if (best >= 0 && dp > hmin) {
                         if (best == 8) {
-                            const int dl = min(e, sk);
-                            sk -= dl;
-                            atomicSub(&s_ex[tid], dl);
+                            const int dl = min(e, sk[j]);
+                            sk[j] -= dl;
+                            atomicSub(&s_ex[slot], dl);
                         } else {
-                            const int dl = min(e, __hip_atomic_load(&s_rc[best][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                            atomicSub(&s_rc[best][tid], dl);
-                            atomicSub(&s_ex[tid], dl);
+                            const int dl = min(e, __hip_atomic_load(&s_rc[best][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            atomicSub(&s_rc[best][slot], dl);
+                            atomicSub(&s_ex[slot], dl);
                             const int bx = dir_dx(best), by = dir_dy(best);
                             const int qlx = lx + bx, qly = ly + by;
                             if (qlx >= 0 && qlx < PT_W && qly >= 0 && qly < PT_H) {
@@ -225,7 +262,8 @@ __global__ void __launch_bounds__(PT_N) k_mf_pr_list(GcDims d, MfTiles tl, int p
                                 atomicAdd(&s_rc[best ^ 1][qt], dl);
                                 atomicAdd(&s_ex[qt], dl);
                             } else {                                        // across the tile edge: straight to global memory
-                                const int q = p + by * d.W + bx;
+                                const int q = pp[j] + by * d.W + bx;
+                                const int y = tyi * PT_H + ly;
                                 atomicAdd(&rc[(size_t)(best ^ 1) * BP + base + q], dl);
                                 atomicAdd(&ex[base + q], dl);
                                 push_tile(b * tiles_per_image + ((y + by) / PT_H) * tl.pt_x + (x + bx) / PT_W, flag_out, list_out, n_out);
@@ -239,25 +277,28 @@ __global__ void __launch_bounds__(PT_N) k_mf_pr_list(GcDims d, MfTiles tl, int p
             if (!__syncthreads_or(act)) break;
         }
         int left = 0;
-        if (inb) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            if (!inb[j]) continue;
             // only the tile's border ring can receive pushes from other tiles during this launch: the interior is
             // owned exclusively, so its write-back is a plain store (L2 atomics are the scarce resource in the
             // early rounds, when nearly every pixel changes)
+            const int slot = tid + j * NT, ly = slot >> 5, p = pp[j];
             const bool ring = lx == 0 || lx == PT_W - 1 || ly == 0 || ly == PT_H - 1;
-            const int e1 = s_ex[tid];
-            if (e1 != e0) { if (ring) atomicAdd(&ex[base + p], e1 - e0); else ex[base + p] = e1; }
+            const int e1 = s_ex[slot];
+            if (e1 != e0[j]) { if (ring) atomicAdd(&ex[base + p], e1 - e0[j]); else ex[base + p] = e1; }
 #pragma unroll
             for (int dir = 0; dir < 8; ++dir) {
-                const int r1 = s_rc[dir][tid];
-                if (r1 != r0[dir]) {
-                    if (ring) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[dir]);
+                const int r1 = s_rc[dir][slot];
+                if (r1 != r0[j][dir]) {
+                    if (ring) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[j][dir]);
                     else rc[(size_t)dir * BP + base + p] = r1;
                 }
             }
-            if (sk != sk0) snk[base + p] = sk;
+            if (sk[j] != sk0[j]) snk[base + p] = sk[j];
             const int d1 = s_d[ly + 1][lx + 1];
-            if (d1 != d0) dist[base + p] = d1;
-            left = (e1 > 0 && d1 < d.P) ? 1 : 0;
+            if (d1 != d0[j]) dist[base + p] = d1;
+            left |= (e1 > 0 && d1 < d.P) ? 1 : 0;
         }
         if (__syncthreads_or(left) && tid == 0) push_tile(tile, flag_out, list_out, n_out);   // still has work
     }
@@ -404,9 +445,15 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             // an active pixel opens at most its own tile: empty blocks only add dispatch time to launches that are pure latency
             static const int grid_per_active = env_int("GGC_MF_GRID_PER_ACTIVE", 2);
             const int grid = (int)std::min<long long>(pr_grid, std::max<long long>(128, (long long)total_active * grid_per_active));
-            for (int phase = 0; phase < launches; ++phase)
-                hipLaunchKernelGGL(k_mf_pr_list, dim3(grid), dim3(PT_N), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
-                                   pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
+            static const int ppt = env_int("GGC_MF_PPT", 1);   // 2 measured 3 % slower end to end: the longer visit outweighs the tiles in flight
+            for (int phase = 0; phase < launches; ++phase) {
+                if (ppt == 2)
+                    hipLaunchKernelGGL((k_mf_pr_list<2>), dim3(grid), dim3(PT_N / 2), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
+                                       pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
+                else
+                    hipLaunchKernelGGL((k_mf_pr_list<1>), dim3(grid), dim3(PT_N), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
+                                       pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
+            }
             GGC_LAUNCH_CHECK(ctx);
             if (trace) {
                 GGC_HIP(ctx, hipStreamSynchronize(st));
