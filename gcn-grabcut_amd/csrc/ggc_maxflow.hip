@@ -183,8 +183,42 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
     if (blockIdx.x == 0 && tid == 0) counters[(phase + 2) % 3] = 0;
     const int tiles_per_image = tl.pt_x * tl.pt_y;
     const size_t BP = (size_t)d.B * d.P;
-    for (int t = blockIdx.x; t < n_in; t += gridDim.x) {
-        const int tile = list_in[t];
+    // The visit latency bounds the dense launches, so the next tile of this block is loaded into registers while the
+    // current one is swept (its list entry one step earlier still).  Safe for the same reason concurrent tiles are:
+    // ring pixels are written back as atomic deltas, interior pixels have no other writer during a launch.
+    constexpr int N_HALO = (PT_H + 2) * (PT_W + 2), HALO_IT = (N_HALO + NT - 1) / NT;
+    struct TileRegs { int e[PPT], sk[PPT], r[PPT][8], hv[HALO_IT]; };
+    auto load_tile = [&](int tile, TileRegs& R) {
+        const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
+        const int tyi = tr / tl.pt_x, txi = tr % tl.pt_x;
+        const int x = txi * PT_W + lx;
+        const size_t base = (size_t)b * d.P;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int y = tyi * PT_H + ((tid + j * NT) >> 5);
+            const bool in = x < d.W && y < d.H;
+            const int p = y * d.W + x;
+            R.e[j] = in ? ex[base + p] : 0;
+            R.sk[j] = in ? snk[base + p] : 0;
+#pragma unroll
+            for (int dir = 0; dir < 8; ++dir) R.r[j][dir] = in ? rc[(size_t)dir * BP + base + p] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < HALO_IT; ++k) {
+            const int i = tid + k * NT;
+            const int gy = tyi * PT_H + i / (PT_W + 2) - 1, gx = txi * PT_W + i % (PT_W + 2) - 1;
+            R.hv[k] = (i < N_HALO && gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
+        }
+    };
+    const int G = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= n_in) return;
+    int tile_next = list_in[t];
+    int tile_next2 = t + G < n_in ? list_in[t + G] : 0;
+    TileRegs N;
+    load_tile(tile_next, N);
+    for (; t < n_in; t += G) {
+        const int tile = tile_next;
         const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
         const int tyi = tr / tl.pt_x, txi = tr % tl.pt_x;
         const int x = txi * PT_W + lx;
@@ -197,32 +231,20 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
             const int slot = tid + j * NT, y = tyi * PT_H + (slot >> 5);
             inb[j] = x < d.W && y < d.H;
             pp[j] = y * d.W + x;
-            e0[j] = 0; sk0[j] = 0;
-            if (inb[j]) { e0[j] = ex[base + pp[j]]; sk0[j] = snk[base + pp[j]]; }
-#pragma unroll
-            for (int dir = 0; dir < 8; ++dir) r0[j][dir] = inb[j] ? rc[(size_t)dir * BP + base + pp[j]] : 0;
-        }
-        // every global load of the visit is issued before the first LDS store waits for one
-        constexpr int N_HALO = (PT_H + 2) * (PT_W + 2), HALO_IT = (N_HALO + NT - 1) / NT;
-        int hv[HALO_IT];
-#pragma unroll
-        for (int k = 0; k < HALO_IT; ++k) {
-            const int i = tid + k * NT;
-            const int gy = tyi * PT_H + i / (PT_W + 2) - 1, gx = txi * PT_W + i % (PT_W + 2) - 1;
-            hv[k] = (i < N_HALO && gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
-        }
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const int slot = tid + j * NT;
+            e0[j] = N.e[j]; sk0[j] = N.sk[j]; sk[j] = sk0[j];
             s_ex[slot] = e0[j];
-            sk[j] = sk0[j];
 #pragma unroll
-            for (int dir = 0; dir < 8; ++dir) s_rc[dir][slot] = r0[j][dir];
+            for (int dir = 0; dir < 8; ++dir) { r0[j][dir] = N.r[j][dir]; s_rc[dir][slot] = r0[j][dir]; }
         }
 #pragma unroll
         for (int k = 0; k < HALO_IT; ++k) {
             const int i = tid + k * NT;
-            if (i < N_HALO) s_d[i / (PT_W + 2)][i % (PT_W + 2)] = hv[k];
+            if (i < N_HALO) s_d[i / (PT_W + 2)][i % (PT_W + 2)] = N.hv[k];
+        }
+        if (t + G < n_in) {                                                // block-uniform
+            tile_next = tile_next2;
+            tile_next2 = t + 2 * G < n_in ? list_in[t + 2 * G] : 0;
+            load_tile(tile_next, N);
         }
         __syncthreads();
         if (tid == 0) flag_in[tile] = 0;                                   // consumed
