@@ -463,17 +463,22 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             ProfScope prof(ctx, st, "maxflow_push");
             // few active pixels: their labels stay exact, so more (cheap) launches beat another global relabel
             // first round: labels go stale fastest while most excess is still moving, an early relabel pays (12 vs 24: +3 %)
-            const int launches = total_active <= tail_active ? tail_launch : (round == 0 ? n_launch0 : n_launch);
+            const bool tail = total_active <= tail_active;
+            const int launches = tail ? tail_launch : (round == 0 ? n_launch0 : n_launch);
+            // sweeps per visit: measured flat from 6 to 12 and worse either side, in the tail too (32 sweeps: -7 % end to
+            // end; a pixel whose admissible arcs saturate keeps the loop alive by relabelling one step per sweep)
+            static const int tail_inner = env_int("GGC_MF_TAIL_INNER", 8);
+            const int sweeps = tail ? tail_inner : n_inner;
             // an active pixel opens at most its own tile: empty blocks only add dispatch time to launches that are pure latency
             static const int grid_per_active = env_int("GGC_MF_GRID_PER_ACTIVE", 2);
             const int grid = (int)std::min<long long>(pr_grid, std::max<long long>(128, (long long)total_active * grid_per_active));
             static const int ppt = env_int("GGC_MF_PPT", 1);   // 2 measured 3 % slower end to end: the longer visit outweighs the tiles in flight
             for (int phase = 0; phase < launches; ++phase) {
                 if (ppt == 2)
-                    hipLaunchKernelGGL((k_mf_pr_list<2>), dim3(grid), dim3(PT_N / 2), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
+                    hipLaunchKernelGGL((k_mf_pr_list<2>), dim3(grid), dim3(PT_N / 2), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, pr_cnt,
                                        pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
                 else
-                    hipLaunchKernelGGL((k_mf_pr_list<1>), dim3(grid), dim3(PT_N), 0, st, d, tl, phase, n_inner, rc, ex, snk, dist, pr_cnt,
+                    hipLaunchKernelGGL((k_mf_pr_list<1>), dim3(grid), dim3(PT_N), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, pr_cnt,
                                        pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
             }
             GGC_LAUNCH_CHECK(ctx);
