@@ -93,35 +93,48 @@ constexpr int MAX_RADIUS = 16;
 struct GaussW { double w[2 * MAX_RADIUS + 1]; int r; };
 
 __device__ __forceinline__ int reflect_sym(int i, int n) { // scipy 'reflect': (b a | a b c | c b)
+    if ((unsigned)i < (unsigned)n) return i;              // interior taps skip the run-time modulo
     if (n == 1) return 0;
     const int period = 2 * n;
     i %= period; if (i < 0) i += period;
     return i < n ? i : period - 1 - i;
 }
 
-// One thread per (pixel, channel).  Same op order as scipy's correlate1d for a
-// symmetric kernel: centre tap first, then pairs from the outermost inwards.
-template <int AXIS>
+// One thread per (pixel, channel); grid = (row segments, rows, images), so no index needs a run-time division.  Same
+// op order as scipy's correlate1d for a symmetric kernel: centre tap first, then pairs from the outermost inwards.
+// R > 0: radius known at compile time (taps unrolled, every load in flight at once); R = 0: g.r at run time.
+template <int AXIS, int R>
 __global__ void __launch_bounds__(256) k_gauss(int H, int W, const float* __restrict__ in, GaussW g,
                                                float scale, int apply_scale, float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;                        // x * 3 + c
+    if (col >= 3 * W) return;
+    const int y = blockIdx.y;
     const size_t n = (size_t)H * W * 3;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* im = in + (size_t)blockIdx.y * n;
-    const int c = (int)(i % 3);
-    const int x = (int)((i / 3) % W);
-    const int y = (int)(i / ((size_t)3 * W));
+    const float* im = in + (size_t)blockIdx.z * n;
+    const int x = col / 3, c = col - 3 * x;
     const int l = AXIS == 0 ? y : x;
     const int len = AXIS == 0 ? H : W;
     auto at = [&](int idx) -> double {
         const int j = reflect_sym(idx, len);
         return (double)(AXIS == 0 ? im[((size_t)j * W + x) * 3 + c] : im[((size_t)y * W + j) * 3 + c]);
     };
-    double tmp = at(l) * g.w[g.r];
-    for (int jj = -g.r; jj < 0; ++jj) tmp += (at(l + jj) + at(l - jj)) * g.w[jj + g.r];
+    double tmp;
+    if (R > 0) {
+        constexpr int RR = R > 0 ? R : 1;
+        double lo[RR], hi[RR];
+        const double mid = at(l);
+#pragma unroll
+        for (int k = 0; k < R; ++k) { lo[k] = at(l - R + k); hi[k] = at(l + R - k); }
+        tmp = mid * g.w[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) tmp += (lo[k] + hi[k]) * g.w[k];
+    } else {
+        tmp = at(l) * g.w[g.r];
+        for (int jj = -g.r; jj < 0; ++jj) tmp += (at(l + jj) + at(l - jj)) * g.w[jj + g.r];
+    }
     float v = (float)tmp;
     if (apply_scale) v = v * scale;
-    out[(size_t)blockIdx.y * n + i] = v;
+    out[(size_t)blockIdx.z * n + (size_t)y * W * 3 + col] = v;
 }
 
 __global__ void __launch_bounds__(256) k_scale(size_t n, const float* __restrict__ in, float scale,
@@ -753,9 +766,15 @@ extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, co
         for (int i = -gw.r; i <= gw.r; ++i) gw.w[i + gw.r] = std::exp(-0.5 / s2 * (double)(i * i));
         const double sum = np_pairwise_sum(gw.w, 2 * gw.r + 1);
         for (int i = 0; i < 2 * gw.r + 1; ++i) gw.w[i] = gw.w[i] / sum;
-        const dim3 grid(cdiv(P * 3, 256), B);
-        hipLaunchKernelGGL((k_gauss<0>), grid, dim3(256), 0, st, H, W, img_a, gw, 1.0f, 0, img_b);
-        hipLaunchKernelGGL((k_gauss<1>), grid, dim3(256), 0, st, H, W, img_b, gw, ratio, 1, img_a);
+        GGC_REQUIRE(ctx, H <= 65535, GGC_E_SHAPE, "H=%d exceeds the launch grid", H);
+        const dim3 grid(cdiv((size_t)W * 3, 256), H, B);
+        if (gw.r == 4) {                                                   // sigma = 1, the pipeline's setting
+            hipLaunchKernelGGL((k_gauss<0, 4>), grid, dim3(256), 0, st, H, W, img_a, gw, 1.0f, 0, img_b);
+            hipLaunchKernelGGL((k_gauss<1, 4>), grid, dim3(256), 0, st, H, W, img_b, gw, ratio, 1, img_a);
+        } else {
+            hipLaunchKernelGGL((k_gauss<0, 0>), grid, dim3(256), 0, st, H, W, img_a, gw, 1.0f, 0, img_b);
+            hipLaunchKernelGGL((k_gauss<1, 0>), grid, dim3(256), 0, st, H, W, img_b, gw, ratio, 1, img_a);
+        }
         km_img = img_a;
     } else {
         hipLaunchKernelGGL(k_scale, dim3(cdiv((size_t)B * P * 3, 256)), dim3(256), 0, st, (size_t)B * P * 3, img_a,
