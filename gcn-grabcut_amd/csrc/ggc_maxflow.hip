@@ -37,7 +37,10 @@ constexpr int RT_ROWS = 256 / RT;      // tile rows covered by one pass of the 2
 constexpr int RT_NJ = RT * RT / 256;   // pixels per thread
 constexpr int PT_W = 32, PT_H = 8;     // push tile (32x16 measured 6 % slower end to end)
 constexpr int PT_N = PT_W * PT_H;      // threads of a push block, one pixel each
-static const int LIST_GRID = [] { const char* e = std::getenv("GGC_MF_LIST_GRID"); return e ? std::max(64, std::atoi(e)) : 8192; }();   // blocks per work-list launch
+// blocks per work-list launch (relabel, push): a block walks several tiles of the list
+static int grid_env(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::max(64, std::atoi(e)) : dflt; }
+static const int LIST_GRID = grid_env("GGC_MF_LIST_GRID", 1024);
+static const int RELAX_GRID = grid_env("GGC_MF_RELAX_GRID", 2 * LIST_GRID), PUSH_GRID = grid_env("GGC_MF_PUSH_GRID", LIST_GRID);
 
 struct MfTiles { int rt_x, rt_y, pt_x, pt_y; };   // tiles per image
 
@@ -88,33 +91,53 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
     if (blockIdx.x == 0 && tid == 0) counters[(phase + 2) % 3] = 0;       // the list after next starts empty
     const int tiles_per_image = tl.rt_x * tl.rt_y;
     const int lx = tid % RT;
-    for (int t = blockIdx.x; t < n_in; t += gridDim.x) {
-        const int tile = list_in[t];
+    // the block's next tile is loaded while the current one is relaxed (a stale halo only delays: the neighbour that
+    // lowers it afterwards puts this tile on the next list)
+    constexpr int N_HALO = (RT + 2) * (RT + 2), HALO_IT = (N_HALO + 255) / 256;
+    struct TileRegs { int hv[HALO_IT], msk[RT_NJ]; };
+    auto load_tile = [&](int tile, TileRegs& R) {
+        const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
+        const int ty0 = (tr / tl.rt_x) * RT, tx0 = (tr % tl.rt_x) * RT;
+        const size_t base = (size_t)b * d.P;
+#pragma unroll
+        for (int k = 0; k < HALO_IT; ++k) {
+            const int i = tid + k * 256;
+            const int gy = ty0 + i / (RT + 2) - 1, gx = tx0 + i % (RT + 2) - 1;
+            R.hv[k] = (i < N_HALO && gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
+        }
+#pragma unroll
+        for (int j = 0; j < RT_NJ; ++j) {
+            const int gy = ty0 + (tid / RT) + RT_ROWS * j, gx = tx0 + lx;
+            R.msk[j] = (gx < d.W && gy < d.H) ? rmask[base + (size_t)gy * d.W + gx] : 0;
+        }
+    };
+    const int G = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= n_in) return;
+    int tile_next = list_in[t];
+    int tile_next2 = t + G < n_in ? list_in[t + G] : 0;
+    TileRegs N;
+    load_tile(tile_next, N);
+    for (; t < n_in; t += G) {
+        const int tile = tile_next;
         const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
         const int tyi = tr / tl.rt_x, txi = tr % tl.rt_x;
         const int tx0 = txi * RT, ty0 = tyi * RT;
         const size_t base = (size_t)b * d.P;
         __syncthreads();                                                   // previous tile's LDS use is over
         if (tid == 0) s_nb = 0;
-        // every global load of the visit is issued before the first LDS store waits for one
-        constexpr int N_HALO = (RT + 2) * (RT + 2), HALO_IT = (N_HALO + 255) / 256;
-        int hv[HALO_IT], msk[RT_NJ], old[RT_NJ];
+        int msk[RT_NJ], old[RT_NJ];
+#pragma unroll
+        for (int j = 0; j < RT_NJ; ++j) msk[j] = N.msk[j];
 #pragma unroll
         for (int k = 0; k < HALO_IT; ++k) {
             const int i = tid + k * 256;
-            const int gy = ty0 + i / (RT + 2) - 1, gx = tx0 + i % (RT + 2) - 1;
-            hv[k] = (i < N_HALO && gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
+            if (i < N_HALO) sd[i / (RT + 2)][i % (RT + 2)] = N.hv[k];
         }
-#pragma unroll
-        for (int j = 0; j < RT_NJ; ++j) {
-            const int ly = (tid / RT) + RT_ROWS * j;
-            const int gy = ty0 + ly, gx = tx0 + lx;
-            msk[j] = (gx < d.W && gy < d.H) ? rmask[base + (size_t)gy * d.W + gx] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < HALO_IT; ++k) {
-            const int i = tid + k * 256;
-            if (i < N_HALO) sd[i / (RT + 2)][i % (RT + 2)] = hv[k];
+        if (t + G < n_in) {                                                // block-uniform
+            tile_next = tile_next2;
+            tile_next2 = t + 2 * G < n_in ? list_in[t + 2 * G] : 0;
+            load_tile(tile_next, N);
         }
         __syncthreads();
         if (tid == 0) flag_in[tile] = 0;                                   // consumed
@@ -413,8 +436,8 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     for (int round = 0; round < max_rounds; ++round) {
         // a launch over a work list costs ~20 us with LIST_GRID mostly empty blocks and ~6 us with a small grid, and the
         // late rounds (a handful of open images) are pure launch latency: size the grids by what the open images can hold
-        const int rl_grid = (int)std::min<size_t>(LIST_GRID, std::max<size_t>(64, (size_t)n_cur * tl.rt_x * tl.rt_y));
-        const int pr_grid = (int)std::min<size_t>(LIST_GRID, std::max<size_t>(64, (size_t)n_cur * tl.pt_x * tl.pt_y / 2));
+        const int rl_grid = (int)std::min<size_t>(RELAX_GRID, std::max<size_t>(64, (size_t)n_cur * tl.rt_x * tl.rt_y));
+        const int pr_grid = (int)std::min<size_t>(PUSH_GRID, std::max<size_t>(64, (size_t)n_cur * tl.pt_x * tl.pt_y / 2));
         // ---- global relabel of the open images
         int relax_launches = 0;
         {
