@@ -436,8 +436,10 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     for (int round = 0; round < max_rounds; ++round) {
         // a launch over a work list costs ~20 us with LIST_GRID mostly empty blocks and ~6 us with a small grid, and the
         // late rounds (a handful of open images) are pure launch latency: size the grids by what the open images can hold
-        const int rl_grid = (int)std::min<size_t>(RELAX_GRID, std::max<size_t>(64, (size_t)n_cur * tl.rt_x * tl.rt_y));
-        const int pr_grid = (int)std::min<size_t>(PUSH_GRID, std::max<size_t>(64, (size_t)n_cur * tl.pt_x * tl.pt_y / 2));
+        // (the grid caps are per 64 open images — a GrabCut lane — and grow with the batch a single call is given)
+        const size_t scale = std::max<size_t>(1, ((size_t)n_cur + 32) / 64);
+        const int rl_grid = (int)std::min<size_t>(RELAX_GRID * scale, std::max<size_t>(64, (size_t)n_cur * tl.rt_x * tl.rt_y));
+        const int pr_grid = (int)std::min<size_t>(PUSH_GRID * scale, std::max<size_t>(64, (size_t)n_cur * tl.pt_x * tl.pt_y / 2));
         // ---- global relabel of the open images
         int relax_launches = 0;
         {
