@@ -210,7 +210,7 @@ def main() -> None:
         stage_ms = {k: round(v[1] / args.steps, 3) for k, v in prof.items() if v[0]}
 
         cpu = parity = None
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:          # the CPU baseline is a rank-0, N=1 leg
             from oracle import oracle as orc       # checker / CPU baseline only
             sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
             n_s = min(args.cpu_sample, batch_size)
