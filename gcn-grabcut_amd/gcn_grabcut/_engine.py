@@ -155,7 +155,7 @@ class Engine:
         d.edge_index = torch.stack([graphs.edge_src, graphs.edge_dst]) if graphs.edge_src.numel() else \
             torch.zeros(2, 0, dtype=torch.int32, device=self.device)
         d.node_ptr32 = graphs.node_ptr
-        return model.predict_probs_device(d)
+        return model.predict_probs_device(d, ctx=self.ctx)
 
     # ------------------------------------------------------------------ P0-P3, S0
     def refine_trimap(self, probs, node_ptr, seg, bgr, thr_fg=0.55, thr_bg=0.55, radius=8, eps=1e-3,

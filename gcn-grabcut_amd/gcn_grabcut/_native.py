@@ -122,6 +122,7 @@ class Context:
             raise GGCError(rc, msg.decode() if msg else "ggc_ctx_create failed")
         self.handle = handle
         self.device_index = int(device_index)
+        self.resident: dict = {}       # which model's weights this context holds ("resgcn" / "gcnnet" -> fingerprint)
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -21,7 +21,11 @@ try:
 except ImportError:  # pragma: no cover
     _TORCH = False
 
+import itertools
+
 from ._constants import N_NODE_FEATS, N_EDGE_FEATS, N_PRIOR_FEATS
+
+_model_uid = itertools.count(1)
 
 TRIMAP_BG = 0        # cv2.GC_BGD
 TRIMAP_FG = 1        # cv2.GC_FGD
@@ -120,7 +124,7 @@ if _TORCH:
             self.head = nn.Linear(D, n_classes)
             self.dropout = dropout
             self._init_weights()
-            self._uploaded = None      # (ctx id, fingerprint) of the weights resident in the library
+            self._uid = next(_model_uid)   # identifies this model in a context's record of resident weights
 
         def _init_weights(self):
             # reference model.py:501-506
@@ -143,8 +147,9 @@ if _TORCH:
 
         def _sync_weights(self, ctx: "_native.Context") -> None:
             sd = self.state_dict()
-            fp = (id(ctx), tuple((k, v.data_ptr(), v._version) for k, v in sd.items()))
-            if self._uploaded == fp:
+            # the record lives on the CONTEXT: another model may have replaced this one's weights there since
+            fp = (self._uid, tuple((k, v.data_ptr(), v._version) for k, v in sd.items()))
+            if ctx.resident.get("resgcn") == fp:
                 return
             ctx.call("ggc_resgcn_configure", self.hidden_channels, self.n_layers)
             for k, v in sd.items():
@@ -153,14 +158,15 @@ if _TORCH:
                 a = v.detach().to(device="cpu", dtype=torch.float32).contiguous().numpy()
                 ctx.call("ggc_resgcn_load_weight", k.encode(), a.ctypes.data, a.size)
             ctx.call("ggc_resgcn_ready")
-            self._uploaded = fp
+            ctx.resident["resgcn"] = fp
 
-        def _run(self, data, want_logits: bool, want_probs: bool):
+        def _run(self, data, want_logits: bool, want_probs: bool, ctx=None):
             if self.training:
                 raise RuntimeError("ResGCNNet on MI355X is inference-only: call .eval() first "
                                    "(training lives in the reference and is out of scope here)")
             dev_index = self._device_index()
-            ctx = _native.get_context(dev_index)
+            if ctx is None:                      # a pipeline replica passes its private context (own scratch arena)
+                ctx = _native.get_context(dev_index)
             self._sync_weights(ctx)
             dev = torch.device("cuda", dev_index)
 
@@ -220,10 +226,11 @@ if _TORCH:
             return self._run(data, False, True)[1].float().cpu().numpy()
 
         @torch.no_grad()
-        def predict_probs_device(self, data) -> "torch.Tensor":
-            """Additive: like predict_probs but the result stays in HBM."""
-            self.eval()
-            return self._run(data, False, True)[1]
+        def predict_probs_device(self, data, ctx=None) -> "torch.Tensor":
+            """Additive: like predict_probs but the result stays in HBM (ctx: library context to run in)."""
+            if self.training:
+                self.eval()
+            return self._run(data, False, True, ctx)[1]
 
         @torch.no_grad()
         def predict_trimap(self, data, segments: np.ndarray,
@@ -287,7 +294,7 @@ if _TORCH:
                 nn.Linear(hidden_channels * (n_layers + 1), hidden_channels), nn.BatchNorm1d(hidden_channels), nn.ReLU(),
                 nn.Dropout(dropout), nn.Linear(hidden_channels, hidden_channels // 2), nn.ReLU(),
                 nn.Linear(hidden_channels // 2, n_classes))
-            self._uploaded: dict = {}
+            self._uid = next(_model_uid)
 
         def _device_index(self) -> int:
             dev = self.head[0].weight.device
@@ -298,8 +305,8 @@ if _TORCH:
 
         def _sync_weights(self, ctx: "_native.Context") -> None:
             sd = self.state_dict()
-            fp = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
-            if self._uploaded.get(id(ctx)) == fp:
+            fp = (self._uid, tuple((k, v.data_ptr(), v._version) for k, v in sd.items()))
+            if ctx.resident.get("gcnnet") == fp:
                 return
             ctx.call("ggc_gcnnet_configure", self._kernel_width, self.n_layers)
             for k, v in sd.items():
@@ -308,7 +315,7 @@ if _TORCH:
                 a = self._padded(k, v.detach().to(device="cpu", dtype=torch.float32).contiguous().numpy())
                 ctx.call("ggc_gcnnet_load_weight", k.encode(), a.ctypes.data, a.size)
             ctx.call("ggc_gcnnet_ready")
-            self._uploaded[id(ctx)] = fp
+            ctx.resident["gcnnet"] = fp
 
         def _padded(self, key: str, a: np.ndarray) -> np.ndarray:
             """Tensor `key` at the kernels' width: zero rows / columns, and BatchNorm statistics (mean 0, var 1, weight 1,
@@ -337,11 +344,12 @@ if _TORCH:
             if key.endswith("edge_inject.proj.0.weight") or key == "input_proj.0.weight": return pad(a, (w, a.shape[1]))
             return pad(a, (w, w))
 
-        def _run(self, data, want_logits: bool, want_probs: bool):
+        def _run(self, data, want_logits: bool, want_probs: bool, ctx=None):
             if self.training:
                 raise RuntimeError("GCNTrimapNet on MI355X is inference-only: call .eval() first")
             dev_index = self._device_index()
-            ctx = _native.get_context(dev_index)
+            if ctx is None:
+                ctx = _native.get_context(dev_index)
             self._sync_weights(ctx)
             dev = torch.device("cuda", dev_index)
             x = data.x
@@ -375,9 +383,10 @@ if _TORCH:
             return self._run(data, False, True)[1].float().cpu().numpy()
 
         @torch.no_grad()
-        def predict_probs_device(self, data) -> "torch.Tensor":
-            self.eval()
-            return self._run(data, False, True)[1]
+        def predict_probs_device(self, data, ctx=None) -> "torch.Tensor":
+            if self.training:
+                self.eval()
+            return self._run(data, False, True, ctx)[1]
 
         @torch.no_grad()
         def predict_trimap(self, data, segments: np.ndarray, threshold_fg: float = 0.55, threshold_bg: float = 0.55) -> np.ndarray:

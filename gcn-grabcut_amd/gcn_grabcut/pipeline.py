@@ -124,14 +124,22 @@ class GCNGrabCutPipeline:
     """
 
     def __init__(self, model, sp_config: Optional[SuperpixelGraphConfig] = None,
-                 gc_config: Optional[GrabCutConfig] = None, device: str = "cuda", grabcut_lanes: int = 4):
+                 gc_config: Optional[GrabCutConfig] = None, device: str = "cuda", grabcut_lanes: int = 4, engine=None):
         from ._engine import get_engine
-        self._eng = get_engine(device)
+        self._eng = engine if engine is not None else get_engine(device)
         self.grabcut_lanes = int(grabcut_lanes)   # additive: concurrent sub-batches of the GrabCut stage (batched calls only)
         self.model = model.to(self._eng.device)
         self.device = device
         self.sp_config = sp_config or SuperpixelGraphConfig()
         self.gc_config = gc_config or GrabCutConfig()
+
+    def replica(self, grabcut_lanes: int = 1) -> "GCNGrabCutPipeline":
+        """Additive: a pipeline over the same model with a private library context (own scratch arena), so that it can
+        run CONCURRENTLY with this one from another host thread on another HIP stream — batch k+1's SLIC / graph / GCN
+        stages then run under batch k's GrabCut, whose max-flow leaves most of the GPU idle."""
+        from ._engine import Engine
+        return GCNGrabCutPipeline(self.model, self.sp_config, self.gc_config, self.device, grabcut_lanes,
+                                  engine=Engine(self._eng.index, private_context=True))
 
     # ------------------------------------------------------------ batched, device resident
     def segment_batch_device(self, bgr, threshold_fg: float = 0.55, threshold_bg: float = 0.55,
@@ -161,7 +169,8 @@ class GCNGrabCutPipeline:
             timing["data_prep"] = 0.0          # the graph is already in HBM: nothing to copy
 
         t = tick()
-        self.model.eval()
+        if self.model.training:
+            self.model.eval()
         probs = eng.predict_probs(self.model, graphs)
         trimap = eng.refine_trimap(probs, graphs.node_ptr, seg, bgr, threshold_fg, threshold_bg, filter_radius,
                                    1e-3, edge_aware)

@@ -192,3 +192,39 @@ def test_one_sided_trimap_is_reseeded_and_cpu_device_is_refused():
         model.head.bias.copy_(torch.tensor([-20.0, -20.0, 20.0]))     # everything "foreground"
     res = GCNGrabCutPipeline(model, device="cuda").segment(_img(80, 80))
     assert set(np.unique(res.trimap)) & {0, 2}                        # _seed_from_prior put background back
+
+
+def test_pipeline_replicas_run_concurrently_with_identical_results(pipe128):
+    """replica(): private library contexts, own HIP streams and host threads — two different batches segmented at the
+    same time give exactly what each gives alone (scratch arenas, weights and streams are per replica)."""
+    import threading
+    from gcn_grabcut.synthetic import synthetic_batch
+    pipe, _ = pipe128
+    dev = pipe._eng.device
+    batches = [pipe._eng.to_device(synthetic_batch(6, 150, 200, config_id=3, first_index=10 * i)) for i in range(3)]
+    keys = ("segments", "trimap", "binary_mask", "gc_mask")
+    alone = [{k: pipe.segment_batch_device(b)[k].clone() for k in keys} for b in batches]
+    torch.cuda.synchronize(dev)
+    pipes = [pipe, pipe.replica(), pipe.replica()]
+    streams = [torch.cuda.Stream(dev) for _ in pipes]
+    got, errors = [None] * 3, []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[i]):
+                for _ in range(3):                                   # a few rounds each, so the stages really interleave
+                    got[i] = pipes[i].segment_batch_device(batches[i])
+            streams[i].synchronize()
+        except Exception as exc:                                     # surfaced in the main thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(3):
+        for k in keys:
+            assert torch.equal(got[i][k], alone[i][k]), (i, k)

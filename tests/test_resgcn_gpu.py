@@ -35,6 +35,20 @@ def test_forward_matches_oracle(oracle, gpu_ctx, hidden, layers, n):
     assert np.allclose(probs.sum(1), 1.0, atol=1e-6)
 
 
+def test_two_models_alternate_on_one_context(gpu_ctx):
+    """The library context holds ONE set of ResGCN weights: a model must notice that another one replaced its weights
+    there (the record of what is resident lives on the context, not on the model)."""
+    a, _ = seeded_state_dict(64, 2, seed=11)
+    b, _ = seeded_state_dict(32, 3, seed=12)
+    a, b = a.to("cuda").eval(), b.to("cuda").eval()
+    x, ei, ea = superpixel_like_graph(n=150, seed=4)
+    d = _data(x, ei, ea)
+    first_a, first_b = a(d).clone(), b(d).clone()
+    assert torch.equal(a(d), first_a)            # a again after b used the same context
+    assert torch.equal(b(d), first_b)
+    assert not torch.equal(first_a, first_b)
+
+
 def test_batched_equals_single_and_oracle(oracle, gpu_ctx):
     # reference tests/test.py:294-306 (atol 1e-4), here on the HIP path
     from gcn_grabcut.data import Batch
