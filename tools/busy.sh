@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/busy
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/busy -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $R/gpurun_out/busy.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/busy -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --overlap-pass 0 > $R/gpurun_out/busy.log 2>&1
 python3 - <<PY
 import csv, glob, os, json
 f=sorted(glob.glob("$R/gpurun_out/busy/*/*kernel_trace.csv"), key=lambda p: -os.path.getsize(p))[0]

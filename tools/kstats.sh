@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/kstats
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kstats -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --lanes ${LANES:-1} > $R/gpurun_out/kstats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kstats -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --overlap-pass 0 --lanes ${LANES:-1} > $R/gpurun_out/kstats.log 2>&1
 python3 - <<PY
 import csv, glob
 f=sorted(glob.glob("$R/gpurun_out/kstats/*/*kernel_stats.csv"), key=lambda p: -__import__("os").path.getsize(p))[0]
