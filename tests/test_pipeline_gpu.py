@@ -228,3 +228,10 @@ def test_pipeline_replicas_run_concurrently_with_identical_results(pipe128):
     for i in range(3):
         for k in keys:
             assert torch.equal(got[i][k], alone[i][k]), (i, k)
+    # the packaged form: results in input order, whatever pipeline took which batch
+    outs = pipe.segment_batches_overlapped(batches + batches[:2], n_pipelines=3)
+    assert len(outs) == 5
+    for j, o in enumerate(outs):
+        for k in keys:
+            assert torch.equal(o[k], alone[j % 3][k]), (j, k)
+    assert pipe.grabcut_lanes == 4                                   # restored
