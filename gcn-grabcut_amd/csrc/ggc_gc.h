@@ -25,4 +25,16 @@ __device__ __forceinline__ int dir_nb(const GcDims& d, int y, int x, int dir) {
 int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
             int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists, int32_t* flags);
 
+// Tile geometry shared by the two drivers of the algorithm (ggc_maxflow.hip: one launch per sweep over work lists
+// of tiles of the whole batch; ggc_maxflow_image.hip: one resident workgroup per image, rounds decided on the device).
+constexpr int MF_RT = 32;                          // relabel tile side
+constexpr int MF_PT_W = 32, MF_PT_H = 8;           // push tile
+struct MfTiles { int rt_x, rt_y, pt_x, pt_y; };    // tiles per image
+
+// One workgroup per image runs the whole max-flow (every round of global relabel + push sweeps) in a single launch.
+// Returns GGC_E_UNSUPPORTED without touching anything when the image has more tiles than the kernel's LDS bitmap holds.
+bool maxflow_image_fits(const GcDims& d);
+int maxflow_image(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
+                  int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* err_flag);
+
 } // namespace ggc

@@ -18,6 +18,7 @@
 #include "ggc_math.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace ggc {
@@ -490,7 +491,7 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
                                                      const uint8_t* __restrict__ mask, const int32_t* __restrict__ state,
                                                      const Gmm* __restrict__ gmm, const int32_t* __restrict__ nw,
                                                      int32_t* __restrict__ rc, int32_t* __restrict__ ex,
-                                                     int32_t* __restrict__ snk, int warm) {
+                                                     int32_t* __restrict__ snk, uint8_t* __restrict__ rmask, int warm) {
     // one image per grid row: the image index is uniform, so the two GMMs (140 doubles) come through scalar loads
     const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t BP = (size_t)d.B * d.P;
@@ -515,6 +516,7 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
     // own planes give the arcs towards left / up-left / up / up-right; the mirrored arcs read the neighbour's plane
     const int dirs[4] = {0, 4, 2, 6};
     int32_t inflow = 0;
+    int arcs = 0;                                        // bit dir = residual arc towards dir (ggc_maxflow_image.hip keeps it current)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int dir = dirs[k];
@@ -522,12 +524,16 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
         const int q = dir_nb(d, y, x, dir ^ 1);
         const int32_t c1 = q >= 0 ? nwb[(size_t)k * BP + q] : 0;
         if (warm) {   // keep the n-link flow of the previous iteration: net inflow = sum (residual - capacity)
-            inflow += (rc[(size_t)dir * BP + i] - c0) + (rc[(size_t)(dir ^ 1) * BP + i] - c1);
+            const int32_t ra = rc[(size_t)dir * BP + i], rb = rc[(size_t)(dir ^ 1) * BP + i];
+            inflow += (ra - c0) + (rb - c1);
+            arcs |= (ra > 0 ? 1 << dir : 0) | (rb > 0 ? 1 << (dir ^ 1) : 0);
         } else {
             rc[(size_t)dir * BP + i] = c0;
             rc[(size_t)(dir ^ 1) * BP + i] = c1;
+            arcs |= (c0 > 0 ? 1 << dir : 0) | (c1 > 0 ? 1 << (dir ^ 1) : 0);
         }
     }
+    rmask[i] = (uint8_t)arcs;
     // Warm start (dynamic graph cuts): only the t-links change between GrabCut iterations, and adding a
     // constant to both t-links of a pixel never changes the cut, so the old n-link flow stays a valid
     // preflow: the pixel's new terminal balance is its t-link difference plus what its neighbours sent it.
@@ -632,11 +638,16 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                 hipLaunchKernelGGL((k_gmm_accum<1>), dim3(cdiv(d.P, 256 * BIN_PX), B), dim3(256), 0, st, d, image, mask, state, gmm, comp, acc);
                 hipLaunchKernelGGL(k_gmm_learn, dim3(cdiv(B * 2, 64)), dim3(64), 0, st, B, state, acc, gmm);
                 static const bool warm_ok = [] { const char* e = std::getenv("GGC_MF_WARM"); return !(e && e[0] == '0'); }();
-                hipLaunchKernelGGL(k_build_graph, dim3(cdiv(d.P, 256), B), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk,
+                hipLaunchKernelGGL(k_build_graph, dim3(cdiv(d.P, 256), B), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk, rmask,
                                    (warm_ok && it > 0) ? 1 : 0);
             }
             GGC_LAUNCH_CHECK(ctx);
-            int rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 6 * B + 16, mf_flags);
+            // one resident workgroup per image and no host round trips when the batch can fill the chip that way;
+            // small batches / huge images keep the launch-per-sweep driver, whose tiles spread one image over many CUs
+            static const int img_min_batch = [] { const char* e = std::getenv("GGC_MF_IMAGE_MIN_BATCH"); return e ? std::atoi(e) : 8; }();
+            const bool per_image = img_min_batch >= 0 && B >= img_min_batch && maxflow_image_fits(d);
+            int rcode = per_image ? maxflow_image(ctx, st, d, state, rc, ex, snk, dist, rmask, err + 1)
+                                  : maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 6 * B + 16, mf_flags);
             if (rcode) return rcode;
             hipLaunchKernelGGL(k_gc_relabel, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, state, dist, mask);
             GGC_LAUNCH_CHECK(ctx);
@@ -647,8 +658,9 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
     if (binary) hipLaunchKernelGGL(k_gc_binary, dim3(cdiv(BP, 256)), dim3(256), 0, st, BP, mask, binary);
     GGC_LAUNCH_CHECK(ctx);
     std::vector<int32_t> herr;
-    int rcode = read_i32(ctx, st, err, 1, herr);
+    int rcode = read_i32(ctx, st, err, 2, herr);
     if (rcode) return rcode;
     GGC_REQUIRE(ctx, herr[0] == 0, GGC_E_INVALID_ARG, "mask holds values outside {0,1,2,3}");
+    GGC_REQUIRE(ctx, herr[1] == 0, GGC_E_DEVICE, "max-flow did not converge");
     return GGC_OK;
 }

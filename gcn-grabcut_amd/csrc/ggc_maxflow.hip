@@ -32,17 +32,15 @@
 
 namespace ggc {
 
-constexpr int RT = 32;                 // relabel tile side
+constexpr int RT = MF_RT;              // relabel tile side
 constexpr int RT_ROWS = 256 / RT;      // tile rows covered by one pass of the 256 threads
 constexpr int RT_NJ = RT * RT / 256;   // pixels per thread
-constexpr int PT_W = 32, PT_H = 8;     // push tile (32x16 measured 6 % slower end to end)
+constexpr int PT_W = MF_PT_W, PT_H = MF_PT_H;   // push tile (32x16 measured 6 % slower end to end)
 constexpr int PT_N = PT_W * PT_H;      // threads of a push block, one pixel each
 // blocks per work-list launch (relabel, push): a block walks several tiles of the list
 static int grid_env(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::max(64, std::atoi(e)) : dflt; }
 static const int LIST_GRID = grid_env("GGC_MF_LIST_GRID", 1024);
 static const int RELAX_GRID = grid_env("GGC_MF_RELAX_GRID", 2 * LIST_GRID), PUSH_GRID = grid_env("GGC_MF_PUSH_GRID", LIST_GRID);
-
-struct MfTiles { int rt_x, rt_y, pt_x, pt_y; };   // tiles per image
 
 __device__ __forceinline__ int ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
