@@ -36,5 +36,10 @@ struct MfTiles { int rt_x, rt_y, pt_x, pt_y; };    // tiles per image
 bool maxflow_image_fits(const GcDims& d);
 int maxflow_image(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
                   int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* err_flag);
+// One launch per max-flow, a pool of resident waves over per-image task lists (ggc_maxflow_pool.hip).  rmask must hold the
+// arc masks of rc on entry (k_build_graph writes them).
+bool maxflow_pool_fits(const GcDims& d);
+int maxflow_pool(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
+                 int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* err_flag);
 
 } // namespace ggc

@@ -642,12 +642,13 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                                    (warm_ok && it > 0) ? 1 : 0);
             }
             GGC_LAUNCH_CHECK(ctx);
-            // one resident workgroup per image and no host round trips when the batch can fill the chip that way;
-            // small batches / huge images keep the launch-per-sweep driver, whose tiles spread one image over many CUs
-            static const int img_min_batch = [] { const char* e = std::getenv("GGC_MF_IMAGE_MIN_BATCH"); return e ? std::atoi(e) : 8; }();
-            const bool per_image = img_min_batch >= 0 && B >= img_min_batch && maxflow_image_fits(d);
-            int rcode = per_image ? maxflow_image(ctx, st, d, state, rc, ex, snk, dist, rmask, err + 1)
-                                  : maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 6 * B + 16, mf_flags);
+            // GGC_MF_DRIVER: pool (default) = one launch, task pool of resident waves; image = one workgroup per image;
+            // host = one launch per sweep with host read-backs (also the fallback for images beyond the pool's tile bitmap)
+            static const int driver = [] { const char* e = std::getenv("GGC_MF_DRIVER"); return !e ? 0 : (e[0] == 'i' ? 1 : (e[0] == 'h' ? 2 : 0)); }();
+            int rcode;
+            if (driver == 0 && maxflow_pool_fits(d)) rcode = maxflow_pool(ctx, st, d, state, rc, ex, snk, dist, rmask, err + 1);
+            else if (driver == 1 && maxflow_image_fits(d)) rcode = maxflow_image(ctx, st, d, state, rc, ex, snk, dist, rmask, err + 1);
+            else rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 6 * B + 16, mf_flags);
             if (rcode) return rcode;
             hipLaunchKernelGGL(k_gc_relabel, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, state, dist, mask);
             GGC_LAUNCH_CHECK(ctx);
@@ -661,6 +662,6 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
     int rcode = read_i32(ctx, st, err, 2, herr);
     if (rcode) return rcode;
     GGC_REQUIRE(ctx, herr[0] == 0, GGC_E_INVALID_ARG, "mask holds values outside {0,1,2,3}");
-    GGC_REQUIRE(ctx, herr[1] == 0, GGC_E_DEVICE, "max-flow did not converge");
+    GGC_REQUIRE(ctx, herr[1] == 0, GGC_E_DEVICE, "max-flow did not converge (code %d)", herr[1]);
     return GGC_OK;
 }
