@@ -22,8 +22,10 @@ __device__ __forceinline__ int dir_nb(const GcDims& d, int y, int x, int dir) {
 //   rc   [8][B][P] residual capacities (in/out)     ex, snk [B][P] excess / residual sink capacity (in/out)
 //   dist [B][P] out: distance to the sink in the final residual graph, >= DINF when unreachable (=> foreground)
 //   rmask [B][P] scratch, lists [2B] scratch, flags [2B+1] scratch
+// handoff_active > 0: once the batch is down to that many active pixels the open images are finished by maxflow_image()
+// (err_flag: device word that receives a non-zero code if that launch does not converge).
 int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
-            int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists, int32_t* flags);
+            int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists, int32_t* flags, int32_t* err_flag, int handoff_active);
 
 // Tile geometry shared by the two drivers of the algorithm (ggc_maxflow.hip: one launch per sweep over work lists
 // of tiles of the whole batch; ggc_maxflow_image.hip: one resident workgroup per image, rounds decided on the device).

@@ -642,13 +642,24 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
                                    (warm_ok && it > 0) ? 1 : 0);
             }
             GGC_LAUNCH_CHECK(ctx);
-            // GGC_MF_DRIVER: pool (default) = one launch, task pool of resident waves; image = one workgroup per image;
-            // host = one launch per sweep with host read-backs (also the fallback for images beyond the pool's tile bitmap)
-            static const int driver = [] { const char* e = std::getenv("GGC_MF_DRIVER"); return !e ? 0 : (e[0] == 'i' ? 1 : (e[0] == 'h' ? 2 : 0)); }();
+            // GGC_MF_DRIVER selects who drives the rounds of the max-flow (same kernels' worth of algorithm, same canonical cut):
+            //   host (default)  work lists over the whole batch, one launch per sweep, list sizes read back by the host
+            //   hybrid          host for the rounds that move most of the flow, then one resident workgroup per open image
+            //   image           one resident workgroup per image from the start, rounds decided on the device (1 launch)
+            //   pool            task pool of resident waves with per-XCD image ownership (1 launch)
+            // Measured on MI355X ("max-flow drivers"): host is the fastest at every batch size tried, so it stays
+            // the default; the device-driven ones are kept, tested, as measured alternatives.  Images beyond the per-image
+            // kernels' tile bitmap always take the host driver.
+            static const int driver = [] {
+                const char* e = std::getenv("GGC_MF_DRIVER");
+                return !e ? 2 : (e[0] == 'i' ? 1 : (e[0] == 'p' ? 3 : (e[0] == 'h' && e[1] == 'y' ? 0 : 2)));
+            }();
+            static const int handoff = [] { const char* e = std::getenv("GGC_MF_HANDOFF_PER_IMAGE"); return e ? std::atoi(e) : 16; }();
             int rcode;
-            if (driver == 0 && maxflow_pool_fits(d)) rcode = maxflow_pool(ctx, st, d, state, rc, ex, snk, dist, rmask, err + 1);
+            if (driver == 3 && maxflow_pool_fits(d)) rcode = maxflow_pool(ctx, st, d, state, rc, ex, snk, dist, rmask, err + 1);
             else if (driver == 1 && maxflow_image_fits(d)) rcode = maxflow_image(ctx, st, d, state, rc, ex, snk, dist, rmask, err + 1);
-            else rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 6 * B + 16, mf_flags);
+            else rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 6 * B + 16, mf_flags, err + 1,
+                                 driver == 0 ? handoff * B : 0);
             if (rcode) return rcode;
             hipLaunchKernelGGL(k_gc_relabel, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, state, dist, mask);
             GGC_LAUNCH_CHECK(ctx);

@@ -374,6 +374,11 @@ __global__ void k_done_update(int n_cur, const int32_t* __restrict__ list_cur, c
     const int b = list_cur[i];
     if (active[b] != 0) { list_nxt[atomicAdd(n_open, 1)] = b; atomicAdd(n_open + 7, active[b]); }   // [7]: active pixels in total
 }
+// state array (0 = to do) of the still-open images, for the hand-over to the per-image driver
+__global__ void k_open_state(int B, int n_open, const int32_t* __restrict__ open_list, int32_t* __restrict__ st) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_open) st[open_list[i]] = 0;
+}
 __global__ void k_open_init(int B, const int32_t* __restrict__ state, int32_t* __restrict__ list, int32_t* __restrict__ n_open) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B && !state[b]) list[atomicAdd(n_open, 1)] = b;
@@ -399,7 +404,8 @@ static int env_int(const char* name, int dflt) {
 
 int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
             int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists /*[2B] open-image lists*/,
-            int32_t* flags /*[B] active | [1] n_open | [3] relabel counters | [3] push counters | [1] active total*/) {
+            int32_t* flags /*[B] active | [1] n_open | [3] relabel counters | [3] push counters | [1] active total*/,
+            int32_t* err_flag, int handoff_active) {
     const int B = d.B;
     int32_t* active = flags;
     int32_t* n_open = flags + B;
@@ -482,6 +488,18 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
         if (n_next == 0) return GGC_OK;
         std::swap(list_cur, list_nxt);
         n_cur = n_next;
+        // Hand-over.  The first rounds move most of the flow and keep the whole chip busy from one work list.  What is left
+        // (a few thousand active pixels in a batch of millions) is a chain of tiny dependent launches and read-backs here,
+        // and it is independent per image: one resident workgroup per open image finishes it in a single launch
+        // (ggc_maxflow_image.hip; the arc masks of this round's relabel are current, nothing has been pushed since).
+        if (handoff_active > 0 && total_active <= handoff_active && maxflow_image_fits(d)) {
+            int32_t* st2 = scratch_t<int32_t>(ctx, S_GC_H, (size_t)B);
+            if (!st2) return GGC_E_OOM;
+            GGC_HIP(ctx, hipMemsetAsync(st2, 0xff, sizeof(int32_t) * B, st));
+            hipLaunchKernelGGL(k_open_state, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, B, n_cur, list_cur, st2);
+            GGC_LAUNCH_CHECK(ctx);
+            return maxflow_image(ctx, st, d, st2, rc, ex, snk, dist, rmask, err_flag);
+        }
         // ---- push-relabel sweeps
         {
             ProfScope prof(ctx, st, "maxflow_push");
