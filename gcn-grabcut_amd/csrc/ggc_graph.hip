@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(256) k_node_feats(GDims d, const int32_t* __re
 
 // ---- K11: prior cue 1, raw contrast (wave per node)
 __global__ void __launch_bounds__(256) k_contrast(GDims d, const int32_t* __restrict__ n_nodes,
-                                                  const RegionStats* __restrict__ st, float* __restrict__ contrast) {
+                                                  const RegionStats* __restrict__ st, float two_cs2, float* __restrict__ contrast) {
     const int b = blockIdx.y;
     const int N = n_nodes[b];
     const int lane = threadIdx.x & 63;
@@ -497,7 +497,6 @@ __global__ void __launch_bounds__(256) k_contrast(GDims d, const int32_t* __rest
     if (i >= N) return;
     const RegionStats* s = st + (size_t)b * d.Nmax;
     const float csum = fmaxf((float)(d.H * d.W), 1.0f);   // counts.sum() == H*W exactly in float32 (< 2^24)
-    const float two_cs2 = (float)(2 * 0.40 * 0.40);
     const RegionStats si = s[i];
     float acc = 0.0f;
     for (int j = lane; j < N; j += 64) {
@@ -535,7 +534,7 @@ __device__ __forceinline__ float unit_apply(float v, float mn, float mx) {  // _
 // ---- K12: the rest of compute_auto_prior (block per image)
 __global__ void __launch_bounds__(256) k_prior(GDims d, const int32_t* __restrict__ n_nodes,
                                                const RegionStats* __restrict__ st, float* __restrict__ work /*[B,Nmax,2]*/,
-                                               const float* __restrict__ contrast, float* __restrict__ prior) {
+                                               const float* __restrict__ contrast, float two_ce2, float* __restrict__ prior) {
     __shared__ float sa[256], sb[256];
     __shared__ double dsum[4][256];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -547,7 +546,6 @@ __global__ void __launch_bounds__(256) k_prior(GDims d, const int32_t* __restric
     float* pr = prior + (size_t)b * d.Nmax * 3;
     float mn, mx;
     block_minmax(N, [&](int i) { return ct[i]; }, mn, mx, sa, sb);
-    const float two_ce2 = (float)(2 * 0.45 * 0.45);
     for (int i = tid; i < N; i += 256) {
         const float a = s[i].pcy - 0.5f, c = s[i].pcx - 0.5f;
         const float dd = sqrtf(a * a + c * c);
@@ -756,8 +754,8 @@ extern "C" int ggc_graph_count(ggc_ctx* ctx, ggc_stream stream, int B, int H, in
     hipLaunchKernelGGL(k_node_feats, dim3(B), dim3(256), 0, st, d, n_nodes, stats, feat);
     {
         ProfScope prof(ctx, st, "graph_prior");
-        hipLaunchKernelGGL(k_contrast, rows, dim3(256), 0, st, d, n_nodes, stats, contrast);
-        hipLaunchKernelGGL(k_prior, dim3(B), dim3(256), 0, st, d, n_nodes, stats, work, contrast, prior);
+        hipLaunchKernelGGL(k_contrast, rows, dim3(256), 0, st, d, n_nodes, stats, ctx->prior_two_cs2, contrast);
+        hipLaunchKernelGGL(k_prior, dim3(B), dim3(256), 0, st, d, n_nodes, stats, work, contrast, ctx->prior_two_ce2, prior);
     }
     GGC_LAUNCH_CHECK(ctx);
 
@@ -796,5 +794,13 @@ extern "C" int ggc_graph_fill(ggc_ctx* ctx, ggc_stream stream, float* x, float* 
         hipLaunchKernelGGL(k_fill_edges, dim3(cdiv(max_pairs, 256), B), dim3(256), 0, st, B, ptrs + (B + 1), ptrs,
                            global_ids, po, flag, edge_src, edge_dst, edge_attr);
     GGC_LAUNCH_CHECK(ctx);
+    return GGC_OK;
+}
+
+extern "C" int ggc_graph_prior_sigmas(ggc_ctx* ctx, double centre_sigma, double contrast_sigma) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, centre_sigma > 0.0 && contrast_sigma > 0.0, GGC_E_INVALID_ARG, "prior sigmas must be positive");
+    ctx->prior_two_ce2 = (float)(2 * centre_sigma * centre_sigma);     // python floats, then float32 operands (graph_builder.py:408,415)
+    ctx->prior_two_cs2 = (float)(2 * contrast_sigma * contrast_sigma);
     return GGC_OK;
 }

@@ -75,6 +75,7 @@ struct ggc_ctx {
     ggc::ResgcnWeights model2;             // GCNTrimapNet (same container: host copies by key, device copies)
     ggc::GraphState graph;
     int n_cu = 256;
+    float prior_two_ce2 = (float)(2 * 0.45 * 0.45), prior_two_cs2 = (float)(2 * 0.40 * 0.40);   // compute_auto_prior sigmas (reference defaults)
     int32_t* h_pinned = nullptr;           // page-locked staging for small device -> host reads (no pageable-copy stall)
     static constexpr int H_PINNED_INTS = 4096;
 };

@@ -22,7 +22,7 @@ ERROR_NAMES = {
     -4: "GGC_E_DEVICE", -5: "GGC_E_UNSUPPORTED", -6: "GGC_E_STATE",
 }
 
-_vp, _i, _f, _i64, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64
+_vp, _i, _f, _d, _i64, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64, C.c_uint64
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/ggc.h
 SIGNATURES = {
@@ -36,6 +36,7 @@ SIGNATURES = {
     "ggc_preprocess": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ggc_slic": [_vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _i, _vp, _vp],
     "ggc_slic_enforce_connectivity": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
+    "ggc_graph_prior_sigmas": [_vp, _d, _d],
     "ggc_graph_count": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "ggc_graph_fill": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "ggc_guided_filter": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp],

@@ -136,12 +136,9 @@ class GraphBuilder:
 
 def compute_auto_prior(segments: np.ndarray, lab: np.ndarray, centre_sigma: float = 0.45,
                        contrast_sigma: float = 0.40, device="cuda") -> np.ndarray:
-    """(N, 3) float32 [fg-ness, bg-ness, ambiguity] — reference graph_builder.py:357-444.
-    Only the reference's default sigmas are compiled into the kernels."""
+    """(N, 3) float32 [fg-ness, bg-ness, ambiguity] — reference graph_builder.py:357-444."""
     import torch
     from ._engine import get_engine
-    if centre_sigma != 0.45 or contrast_sigma != 0.40:
-        raise NotImplementedError("non-default prior sigmas are not compiled into the MI355X kernels")
     eng = get_engine(device)
     seg = eng.to_device(np.ascontiguousarray(segments, dtype=np.int32)[None])
     lab_d = eng.to_device(np.ascontiguousarray(lab, dtype=np.float32)[None])
@@ -149,7 +146,11 @@ def compute_auto_prior(segments: np.ndarray, lab: np.ndarray, centre_sigma: floa
     n = torch.tensor([int(segments.max()) + 1], dtype=torch.int32, device=eng.device)
     zeros3 = torch.zeros(1, h, w, 3, device=eng.device)
     zeros1 = torch.zeros(1, h, w, device=eng.device)
-    graphs = eng.build_graphs(seg, n, lab_d, zeros3, zeros1, 4, 0)
+    eng.ctx.call("ggc_graph_prior_sigmas", float(centre_sigma), float(contrast_sigma))
+    try:
+        graphs = eng.build_graphs(seg, n, lab_d, zeros3, zeros1, 4, 0)
+    finally:
+        eng.ctx.call("ggc_graph_prior_sigmas", 0.45, 0.40)     # the pipeline's graphs use the reference defaults
     return graphs.x[:, N_IMAGE_FEATS:].cpu().numpy()
 
 

@@ -144,6 +144,10 @@ int ggc_graph_fill(ggc_ctx* ctx, ggc_stream stream,
                    float* x, float* centroids, float* area_ratio,
                    int32_t* edge_src, int32_t* edge_dst, float* edge_attr, int global_ids);
 
+/* compute_auto_prior(segments, lab, centre_sigma=0.45, contrast_sigma=0.40) (graph_builder.py:357-362): the two sigmas of
+ * the prior used by the NEXT ggc_graph_count calls of this context (defaults = the reference's). */
+int ggc_graph_prior_sigmas(ggc_ctx* ctx, double centre_sigma, double contrast_sigma);
+
 /* ------------------------------------------------------------ M0-M7 ResGCNNet
  * Replaces ResGCNNet (model.py:421-557), eval mode.
  * ggc_resgcn_configure fixes the architecture; ggc_resgcn_load_weight takes

@@ -75,6 +75,8 @@ void ggo_graph_get(const ggo_graph* g, float* node_features /*[N,16]*/, float* p
 void ggo_graph_free(ggo_graph* g);
 void ggo_auto_prior(int H, int W, const int32_t* segments, const float* lab, int n_nodes,
                     float* prior /*[N,3]*/);
+void ggo_auto_prior_sigmas(int H, int W, const int32_t* segments, const float* lab, int n_nodes, double centre_sigma,
+                           double contrast_sigma, float* prior);
 
 /* ---- M0-M7: ResGCNNet.forward (model.py:508-536), eval mode ---- */
 int ggo_resgcn_n_params(int n_layers);

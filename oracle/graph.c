@@ -111,7 +111,8 @@ static float fix_nan(float v, float posinf) { /* np.nan_to_num(nan=0, posinf=1, 
 }
 
 /* compute_auto_prior (graph_builder.py:357-444) */
-void ggo_auto_prior(int H, int W, const int32_t* seg, const float* lab, int N, float* prior) {
+void ggo_auto_prior_sigmas(int H, int W, const int32_t* seg, const float* lab, int N, double centre_sigma, double contrast_sigma,
+                           float* prior) {
     const size_t P = (size_t)H * W;
     double* acc = (double*)calloc((size_t)N * 6, sizeof(double)); /* cnt, l, a, b, y, x */
     for (int y = 0; y < H; ++y)
@@ -138,7 +139,7 @@ void ggo_auto_prior(int H, int W, const int32_t* seg, const float* lab, int N, f
     if (!(csum > 1.0f)) csum = 1.0f;
     float* contrast = (float*)malloc((size_t)N * sizeof(float));
     float* row = (float*)malloc((size_t)N * sizeof(float));
-    const float two_cs2 = (float)(2 * 0.40 * 0.40);
+    const float two_cs2 = (float)(2 * contrast_sigma * contrast_sigma);   /* python float, then a float32 operand */
     for (int i = 0; i < N; ++i) {
         for (int j = 0; j < N; ++j) {
             const float cd = norm3(ml + 3 * i, ml + 3 * j);
@@ -150,7 +151,7 @@ void ggo_auto_prior(int H, int W, const int32_t* seg, const float* lab, int N, f
         contrast[i] = pairwise_f32(row, N);
     }
     unit_norm(contrast, N);
-    const float two_ce2 = (float)(2 * 0.45 * 0.45);
+    const float two_ce2 = (float)(2 * centre_sigma * centre_sigma);
     float* fg = (float*)malloc((size_t)N * sizeof(float));
     for (int i = 0; i < N; ++i) {
         const float a = ce[2 * i] - 0.5f, b = ce[2 * i + 1] - 0.5f;
@@ -195,6 +196,10 @@ void ggo_auto_prior(int H, int W, const int32_t* seg, const float* lab, int N, f
     }
     (void)P;
     free(acc); free(counts); free(safe); free(ml); free(ce); free(contrast); free(row); free(fg); free(bc); free(bg);
+}
+
+void ggo_auto_prior(int H, int W, const int32_t* seg, const float* lab, int N, float* prior) {   /* the reference's defaults (:357-362) */
+    ggo_auto_prior_sigmas(H, W, seg, lab, N, 0.45, 0.40, prior);
 }
 
 ggo_graph* ggo_graph_build(int H, int W, const int32_t* seg, const float* lab, const float* hsv,

@@ -241,13 +241,13 @@ def graph_build(segments, lab, hsv, grad, connectivity=4, n_nonlocal=4):
     return out
 
 
-def auto_prior(segments, lab):
+def auto_prior(segments, lab, centre_sigma=0.45, contrast_sigma=0.40):
     L = lib()
     seg = np.ascontiguousarray(segments, dtype=np.int32)
     h, w = seg.shape
     n = int(seg.max()) + 1
     out = np.empty((n, 3), np.float32)
-    L.ggo_auto_prior(_i(h), _i(w), _p(seg), _p(f32(lab)), _i(n), _p(out))
+    L.ggo_auto_prior_sigmas(_i(h), _i(w), _p(seg), _p(f32(lab)), _i(n), _d(centre_sigma), _d(contrast_sigma), _p(out))
     return out
 
 

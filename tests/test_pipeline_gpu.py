@@ -235,3 +235,62 @@ def test_pipeline_replicas_run_concurrently_with_identical_results(pipe128):
         for k in keys:
             assert torch.equal(o[k], alone[j % 3][k]), (j, k)
     assert pipe.grabcut_lanes == 4                                   # restored
+
+
+def _check_against_oracle(oracle, pipe, sd, imgs, hidden, layers, n_seg):
+    """label map, edge_index, node input, probabilities, trimap and mask of a device batch against the oracle chain"""
+    out = pipe.segment_batch_device(pipe._eng.to_device(imgs))
+    g = out["graphs"]
+    seg, tri, binm = out["segments"].cpu().numpy(), out["trimap"].cpu().numpy(), out["binary_mask"].cpu().numpy()
+    st = _np_state(sd)
+    for i in range(len(imgs)):
+        want = oracle.segment(imgs[i], st, hidden, layers, n_segments=n_seg, seed=i)
+        assert np.array_equal(seg[i], want["segments"]), i                        # label map: bit-exact
+        n0, n1, e0, e1 = g.node_ptr_host[i], g.node_ptr_host[i + 1], g.edge_ptr_host[i], g.edge_ptr_host[i + 1]
+        ei = np.stack([g.edge_src[e0:e1].cpu().numpy(), g.edge_dst[e0:e1].cpu().numpy()]).astype(np.int64) - n0
+        assert np.array_equal(ei, want["graph"]["edge_index"]), i                 # edge_index: integer-exact, reference order
+        assert np.abs(g.x[n0:n1].cpu().numpy() - want["x"]).max() <= 2e-5
+        assert np.abs(out["probs"][n0:n1].cpu().numpy() - want["probs"]).max() <= 1e-4
+        assert (tri[i] == want["trimap"]).mean() >= 0.9999, i
+        if np.array_equal(tri[i], want["trimap"]):
+            assert np.array_equal(binm[i], want["binary_mask"]), i
+        assert oracle.iou(binm[i], want["binary_mask"]) >= 0.99 or want["binary_mask"].sum() == 0
+    return out
+
+
+def test_config0_single_320x240_500_superpixels(oracle):
+    """BASELINE.json configs[0]: one 320x240 image, ~500 superpixels, through the reference's single-image entry point
+    (reference inference.py:118-141 -> pipeline.py:265-352)."""
+    from gcn_grabcut import GCNGrabCutPipeline, SuperpixelGraphConfig
+    from gcn_grabcut.synthetic import synthetic_batch
+    model, sd = seeded_state_dict(128, 6, seed=0)
+    pipe = GCNGrabCutPipeline(model.eval(), sp_config=SuperpixelGraphConfig(n_segments=500), device="cuda")
+    img = synthetic_batch(1, 240, 320, config_id=1)[0]
+    r = pipe.segment(img)
+    want = oracle.segment(img, _np_state(sd), 128, 6, n_segments=500, seed=0)
+    assert 480 <= want["graph"]["n_nodes"] <= 560                                  # SURVEY section 8: N ~ 532
+    assert np.array_equal(r.segments, want["segments"])
+    assert (r.trimap == want["trimap"]).mean() >= 0.9999
+    if np.array_equal(r.trimap, want["trimap"]):
+        assert np.array_equal(r.binary_mask, want["binary_mask"])
+    assert oracle.iou(r.binary_mask, want["binary_mask"]) >= 0.99 or want["binary_mask"].sum() == 0
+    assert r.overlay.shape == (240, 320, 3) and r.rgba.shape == (240, 320, 4)
+    for key in ("graph_build", "data_prep", "gcn_inference", "grabcut", "postprocess"):
+        assert key in r.timing
+    _check_against_oracle(oracle, pipe, sd, img[None], 128, 6, 500)
+
+
+def test_config4_1080p_4000_superpixels(oracle):
+    """BASELINE.json configs[4]'s per-image shape: 1920x1080, ~4000 superpixels (N ~ 3.8k: the > 782-node aggregation route,
+    14.7 M kNN distances, 8.3 M n-links per image), one image and a batch of two against the oracle."""
+    from gcn_grabcut import GCNGrabCutPipeline, SuperpixelGraphConfig
+    from gcn_grabcut.synthetic import synthetic_batch
+    model, sd = seeded_state_dict(128, 6, seed=0)
+    pipe = GCNGrabCutPipeline(model.eval(), sp_config=SuperpixelGraphConfig(n_segments=4000), device="cuda")
+    imgs = synthetic_batch(2, 1080, 1920, config_id=5)
+    out = _check_against_oracle(oracle, pipe, sd, imgs, 128, 6, 4000)
+    n = np.diff(out["graphs"].node_ptr_host)
+    assert (n > 3500).all() and (n < 4100).all()                                   # SURVEY section 8: N ~ 3833
+    one = pipe.segment_batch_device(pipe._eng.to_device(imgs[1:]))                 # batch of one == its row of the batch of two
+    assert torch.equal(one["segments"][0], out["segments"][1]) and torch.equal(one["trimap"][0], out["trimap"][1])
+    assert torch.equal(one["binary_mask"][0], out["binary_mask"][1])
