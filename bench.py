@@ -11,12 +11,15 @@ DUTS-shaped images that are already resident in HBM:
                                 trimap -> GrabCut -> clean-up, batch 256 of 400x300 per GPU
     --workload gcn              configs[1]: ResGCNNet forward only on 64 pre-built graphs
 
-Rank 0 prints ONE JSON line: BASELINE.json's metric (images/s), the roofline of
-the dominant kernel named by the north star (the GCNConv scatter-gather, timed
-with HIP events on its launch stream inside the timed region), parity against
-the CPU oracle on a sample, and the oracle timed on that bounded sample.
-Weights are a seeded random init (the reference ships no checkpoint).  Images
-shard across ranks with no data-path collective; RCCL only gathers the timing.
+Rank 0 prints ONE JSON line: BASELINE.json's metric (images/s; inputs resident in HBM when the clock starts), the
+roofline of the kernel the north star grades (the GCNConv scatter-gather, timed with HIP events on its launch stream
+inside the timed region), the whole path against the HBM roofline (`pipeline_roofline`: SURVEY section 8(d)'s
+algorithmic bytes per image over the step time) with a per-stage table, the rate with the host->device copy of the
+batch inside the clock (`h2d_inclusive`, informational), parity against the CPU oracle on a sample, and the oracle
+timed on the host cores: one thread per stage group, and all cores with one worker process per image.
+Weights are a seeded random init (the reference ships no checkpoint).  Images shard across ranks with no data-path
+collective; RCCL only gathers one 64-byte record per rank after the timed region (gcn_grabcut/distributed.py).
+`python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run) before touching a GPU.
 """
 from __future__ import annotations
 
@@ -80,18 +83,56 @@ def agg_bytes(n_nodes: int, n_edges: int, d: int, n_graphs: int) -> int:
             + n_nodes * 4 + d * 4)
 
 
+def path_bytes_per_image(p: int, n: float, e: float, d: int = HIDDEN) -> dict:
+    """compulsory HBM bytes per image and stage, inputs / outputs in HBM and perfect reuse on chip
+    (P pixels, N regions, E directed edges, D hidden).  ~44 MB at 400x300 / 600 regions."""
+    agg = 2 * n * d * 4 + (e + n) * 4 + (n + 1) * 4 + n * 4 + d * 4            # one unfused aggregation pass
+    return {
+        "colour_prep": 35 * p,                                                 # G0: read 3P, write lab/hsv/gray/grad 32P
+        "slic": 16 * p,                                                        # G1: read 12P, write the label map 4P
+        "graph": 36 * p + (n * 19 + e * 5) * 4 + e * 16,                       # G2-G8: read seg + lab/hsv/grad, write x / edges
+        "gcn": 7 * agg + 11 * 2 * n * d * 4 + e * (5 * 4 + 2 * 64 * 4),        # M1-M7: 7 gathers, ~11 dense N x D passes, edge MLP
+        "trimap": 9 * p,                                                       # P0-P2: read gray + seg, write the trimap
+        "grabcut": 5 * (16 + 3 + 1) * p + 32 * p,                              # C0-C5: t-links, image, mask per iteration; n-links once
+        "cleanup_compose": 9 * p,                                              # K0, O0
+    }
+
+
+def launch_own_ranks(n: int) -> None:
+    """`--gpus N` given without a launcher: start N ranks with torch.distributed.run as a CHILD process, before this
+    process has touched a GPU (device_count() does not initialise one on this image), and leave with its exit code."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+PMC_SUMMARY = "profiles/r02_pmc_bench_hbm.json"
+
+
 def pmc_traffic(workload: str, batch: int):
     """HBM bytes per launch of the graded kernel from the PMC counters.  Counters cannot be read from inside a
     timed run (rocprofv3 --pmc serialises every dispatch), so this is the committed summary of the separate
-    FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/r01_pmc_bench_hbm.json, tools/pmc_bench.sh);
-    null for any other workload or batch size."""
+    FETCH_SIZE / WRITE_SIZE passes over this same command (PMC_SUMMARY, written by tools/pmc_bench.sh; the round-1 file
+    as a fallback); null for any other workload or batch size.  -> (bytes, source file)"""
     if workload != "full" or batch != 256:
-        return None
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench_hbm.json")) as fh:
-            return int(json.load(fh)["kernels"]["k_aggregate_graph<128, 0, 32, true>"]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+    for rel in (PMC_SUMMARY, "profiles/r01_pmc_bench_hbm.json"):
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), rel)) as fh:
+                return int(json.load(fh)["kernels"]["k_aggregate_graph<128, 0, 32, true>"]["hbm_bytes_per_launch"]), rel
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def main() -> None:
@@ -108,15 +149,22 @@ def main() -> None:
     ap.add_argument("--pipelines", type=int, default=1, help="full workload: pipelines (private contexts, own HIP streams and "
                     "host threads) that take the timed steps in turn, so consecutive batches overlap")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default 256 full / 64 gcn)")
-    ap.add_argument("--cpu-sample", type=int, default=40, help="images timed on the CPU oracle, ~12 s of one core (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="images run through the CPU oracle on ONE thread (per-stage times, "
+                    "parity sample; ~6 s of one core; 0 = no CPU leg at all)")
+    ap.add_argument("--cpu-all", type=int, default=256, help="images of the all-cores CPU leg, one worker process per image (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the all-cores leg (default: the cores this "
+                    "process may use, at most 16 = one GPU's share of the host)")
+    ap.add_argument("--h2d-steps", type=int, default=3, help="extra timed steps that include the host->device copy of the batch (0 = skip)")
     args = ap.parse_args()
     batch_size = args.batch or (256 if args.workload == "full" else 64)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_own_ranks(args.gpus)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -161,20 +209,27 @@ def main() -> None:
                 return
             import threading
 
+            errors = []
+
             def worker(i):
-                torch.cuda.set_device(dev)
-                with torch.cuda.stream(streams[i]):
-                    for s in range(i, n, n_pipes):
-                        out = pipes[i].segment_batch_device(bgr, compose=True)
-                        if s == n - 1:
-                            last["out"] = out
-                streams[i].synchronize()
+                try:
+                    torch.cuda.set_device(dev)
+                    with torch.cuda.stream(streams[i]):
+                        for s in range(i, n, n_pipes):
+                            out = pipes[i].segment_batch_device(bgr, compose=True)
+                            if s == n - 1:
+                                last["out"] = out
+                    streams[i].synchronize()
+                except Exception as exc:                   # re-raised below: a timing over work that never ran is worthless
+                    errors.append(exc)
 
             threads = [threading.Thread(target=worker, args=(i,), name=f"ggc-pipe{i}") for i in range(n_pipes)]
             for th in threads:
                 th.start()
             for th in threads:
                 th.join()
+            if errors:
+                raise errors[0]
     else:
         rng = np.random.default_rng(20_000 + rank)
         host_graphs = [synthetic_region_graph(int(rng.integers(585, 618)), rng) for _ in range(batch_size)]
@@ -218,10 +273,29 @@ def main() -> None:
     for c in ctxs:
         c.profile_enable(False)
 
+    elapsed_rank = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- informational: the same steps with the host->device copy of the batch inside the clock (SURVEY 8(d) "end-to-end")
+    h2d = None
+    if args.workload == "full" and args.h2d_steps > 0 and n_pipes == 1:
+        pinned = torch.from_numpy(host_imgs).pin_memory()
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.h2d_steps):
+            last["out"] = pipe.segment_batch_device(pinned.to(dev, non_blocking=True), compose=True)
+        sync_all()
+        e1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e1 = float(t.item())
+        h2d = {"value": round(batch_size * world * args.h2d_steps / e1, 2), "unit": "images/s", "steps": args.h2d_steps,
+               "ms_per_step": round(e1 / args.h2d_steps * 1e3, 3), "bytes_per_step_per_gpu": int(host_imgs.nbytes),
+               "note": "pinned host batch copied to the device inside the timed region, then the same step"}
 
     # ---- informational second pass: consecutive batches overlapped (batch k+1's SLIC / graph / GCN under batch k's GrabCut).
     # Not the contract's number: per-kernel event timing is meaningless under overlap, so `value` and `roofline` stay serial.
@@ -253,6 +327,88 @@ def main() -> None:
     images = batch_size * world * args.steps
     value = images / elapsed
 
+    # ---- CPU oracle legs (checker and reported baseline; never part of the timed region)
+    from gcn_grabcut.distributed import RankRecord, gather_records, summarise
+    rec = RankRecord(n_images=batch_size * args.steps, seconds=elapsed_rank)
+    cpu = parity = None
+    if args.cpu_sample > 0:
+        from oracle import oracle as orc               # checker / CPU baseline only
+        sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+        # every rank checks a few images of ITS shard (the gathered record carries the tallies); rank 0 of a single-GPU
+        # run checks the full sample and times it
+        n_s = min(args.cpu_sample if world == 1 else 2, batch_size)
+        if args.workload == "full":
+            out = last["out"]
+            g = out["graphs"]
+            seg_g, tri_g = out["segments"][:n_s].cpu().numpy(), out["trimap"][:n_s].cpu().numpy()
+            bin_g, probs_g = out["binary_mask"][:n_s].cpu().numpy(), out["probs"].cpu().numpy()
+            stage_s = {"graph_build": 0.0, "gcn_inference": 0.0, "grabcut": 0.0, "postprocess": 0.0}
+            t1 = time.perf_counter()
+            ref = []
+            for i in range(n_s):
+                tm = {}
+                ref.append(orc.segment(host_imgs[i], sd, HIDDEN, LAYERS, n_segments=N_SEGMENTS, seed=i, timing=tm))
+                for k in stage_s:
+                    stage_s[k] += tm[k]
+            dt = time.perf_counter() - t1
+            ious, dl, ei_ok = [], 0.0, []
+            esrc, edst = g.edge_src.cpu().numpy().astype(np.int64), g.edge_dst.cpu().numpy().astype(np.int64)
+            for i, r in enumerate(ref):
+                n0, n1 = int(g.node_ptr_host[i]), int(g.node_ptr_host[i + 1])
+                e0, e1 = int(g.edge_ptr_host[i]), int(g.edge_ptr_host[i + 1])
+                ei_ok.append(np.array_equal(np.stack([esrc[e0:e1], edst[e0:e1]]) - n0, r["graph"]["edge_index"]))
+                if n1 - n0 == r["probs"].shape[0]:
+                    dl = max(dl, float(np.abs(probs_g[n0:n1] - r["probs"]).max()))
+                ious.append(orc.iou(bin_g[i], r["binary_mask"]) if r["binary_mask"].any() or bin_g[i].any() else 1.0)
+            lab_ok = [np.array_equal(seg_g[i], ref[i]["segments"]) for i in range(n_s)]
+            tri_ok = [np.array_equal(tri_g[i], ref[i]["trimap"]) for i in range(n_s)]
+            msk_ok = [np.array_equal(bin_g[i], ref[i]["binary_mask"]) for i in range(n_s)]
+            rec.sum_iou, rec.n_iou, rec.n_checked = float(np.sum(ious)), n_s, n_s
+            rec.n_label_exact, rec.n_trimap_exact, rec.n_mask_exact = float(np.sum(lab_ok)), float(np.sum(tri_ok)), float(np.sum(msk_ok))
+            parity = {
+                "sample": n_s,
+                "label_map_exact_pct": round(100.0 * float(np.mean(lab_ok)), 2),
+                "edge_index_exact_pct": round(100.0 * float(np.mean(ei_ok)), 2),
+                "trimap_pixel_match_pct": round(100.0 * float(np.mean([(tri_g[i] == ref[i]["trimap"]).mean() for i in range(n_s)])), 4),
+                "trimap_exact_images_pct": round(100.0 * float(np.mean(tri_ok)), 2),
+                "mask_exact_pct": round(100.0 * float(np.mean(msk_ok)), 2),
+                "max_abs_dprob": dl, "mean_mask_iou": round(float(np.mean(ious)), 6), "min_mask_iou": round(float(np.min(ious)), 6),
+            }
+            what = f"{n_s} of the {batch_size} images, full pipeline"
+            per_stage = {k: round(v / n_s * 1e3, 2) for k, v in stage_s.items()}
+        else:
+            probs_g = last["out"].cpu().numpy()
+            off = np.cumsum([0] + [x.shape[0] for x, _, _ in host_graphs])
+            orc.resgcn_forward(sd, HIDDEN, LAYERS, *host_graphs[0])          # warm
+            t1 = time.perf_counter()
+            ref = [orc.resgcn_forward(sd, HIDDEN, LAYERS, x, ei, ea) for x, ei, ea in host_graphs[:n_s]]
+            dt = time.perf_counter() - t1
+            parity = {"sample": n_s, "max_abs_dprob": max(float(np.abs(probs_g[off[i]:off[i + 1]] - ref[i][1]).max())
+                                                          for i in range(n_s))}
+            what = f"{n_s} of the {batch_size} graphs, GCN forward only"
+            per_stage = None
+        if rank == 0 and world == 1:                    # the CPU baseline is a rank-0, N=1 leg
+            host_cores = len(os.sched_getaffinity(0))
+            single = {"value": round(n_s / dt, 3), "unit": "images/s", "cores": 1, "sample": what,
+                      "ms_per_image_by_stage": per_stage}
+            cpu = {"value": single["value"], "unit": "images/s", "cores": 1, "kind": "port",
+                   "sample": f"{what}; C oracle (CPU restatement of the OpenCV + scikit-image + PyG path), 1 thread; host has {host_cores} cores",
+                   "single_thread": single, "all_cores": None}
+            if args.workload == "full" and args.cpu_all > 0:
+                from oracle import cpu_pool
+                workers = args.cpu_workers if args.cpu_workers > 0 else min(host_cores, 16)
+                n_all = args.cpu_all
+                dt_all, res = cpu_pool.run(range(n_all), 0, workers, sd, HIDDEN, LAYERS, N_SEGMENTS, H, W, 3)
+                cpu["all_cores"] = {"value": round(n_all / dt_all, 3), "unit": "images/s", "cores": workers,
+                                    "sample": f"{n_all} images of the same generator, one worker process per image "
+                                              f"(reference dataset.py:496-520 pattern), {workers} processes",
+                                    "mean_worker_s_per_image": round(float(np.mean([r["seconds"] for r in res])), 4)}
+                # the reported baseline is the better of the two legs; `cores` = the threads it really used
+                cpu.update(value=cpu["all_cores"]["value"], cores=workers,
+                           sample=f"{n_all} images, full pipeline, C oracle on {workers} worker processes (host has {host_cores} cores); "
+                                  f"single thread: {single['value']} images/s")
+    records = gather_records(rec, dev if world > 1 else None)      # the path's only collective: 64 bytes per rank
+
     if rank == 0:
         if args.workload == "full":
             g = last["out"]["graphs"]
@@ -263,59 +419,56 @@ def main() -> None:
         agg_avg_s = agg_ms / 1e3 / max(launches, 1)
         b_launch = agg_bytes(n_nodes, n_edges, HIDDEN, batch_size)
         achieved = b_launch / agg_avg_s / 1e9 if launches else 0.0
+        traffic, traffic_src = pmc_traffic(args.workload, batch_size)
         roofline = {
             "kernel": "k_aggregate_graph<128,0,32,gated> (GCNConv scatter-gather, graph slice resident in LDS, fused gate/GELU/residual epilogue)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload, batch_size),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": (f"{traffic_src}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, not this run"
+                               if traffic_src else None),
             "bytes_per_launch": b_launch, "avg_launch_us": round(agg_avg_s * 1e6, 2), "launches": launches,
             "event_pair_overhead_us": round(ctx.profile_query("#event_pair_overhead")[1] * 1e3, 2),
             # informational: bytes of all gathered neighbour rows per second; they are served from LDS
             "effective_gather_gbs": round((n_edges + n_nodes) * HIDDEN * 4 / agg_avg_s / 1e9, 1) if launches else 0.0,
         }
         stage_ms = {k: round(v[1] / args.steps, 3) for k, v in prof.items() if v[0]}
-
-        cpu = parity = None
-        if args.cpu_sample > 0 and world == 1:          # the CPU baseline is a rank-0, N=1 leg
-            from oracle import oracle as orc       # checker / CPU baseline only
-            sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
-            n_s = min(args.cpu_sample, batch_size)
-            if args.workload == "full":
-                out = last["out"]
-                seg_g, tri_g = out["segments"][:n_s].cpu().numpy(), out["trimap"][:n_s].cpu().numpy()
-                bin_g, probs_g = out["binary_mask"][:n_s].cpu().numpy(), out["probs"].cpu().numpy()
-                t1 = time.perf_counter()
-                ref = [orc.segment(host_imgs[i], sd, HIDDEN, LAYERS, n_segments=N_SEGMENTS, seed=i) for i in range(n_s)]
-                dt = time.perf_counter() - t1
-                ious, dl, ei_ok = [], 0.0, []
-                esrc, edst = g.edge_src.cpu().numpy().astype(np.int64), g.edge_dst.cpu().numpy().astype(np.int64)
-                for i, r in enumerate(ref):
-                    n0, n1 = int(g.node_ptr_host[i]), int(g.node_ptr_host[i + 1])
-                    e0, e1 = int(g.edge_ptr_host[i]), int(g.edge_ptr_host[i + 1])
-                    ei_ok.append(np.array_equal(np.stack([esrc[e0:e1], edst[e0:e1]]) - n0, r["graph"]["edge_index"]))
-                    if n1 - n0 == r["probs"].shape[0]:
-                        dl = max(dl, float(np.abs(probs_g[n0:n1] - r["probs"]).max()))
-                    ious.append(orc.iou(bin_g[i], r["binary_mask"]) if r["binary_mask"].any() or bin_g[i].any() else 1.0)
-                parity = {
-                    "sample": n_s,
-                    "label_map_exact_pct": round(100.0 * float(np.mean([np.array_equal(seg_g[i], ref[i]["segments"]) for i in range(n_s)])), 2),
-                    "edge_index_exact_pct": round(100.0 * float(np.mean(ei_ok)), 2),
-                    "trimap_pixel_match_pct": round(100.0 * float(np.mean([(tri_g[i] == ref[i]["trimap"]).mean() for i in range(n_s)])), 4),
-                    "mask_exact_pct": round(100.0 * float(np.mean([np.array_equal(bin_g[i], ref[i]["binary_mask"]) for i in range(n_s)])), 2),
-                    "max_abs_dprob": dl, "mean_mask_iou": round(float(np.mean(ious)), 6), "min_mask_iou": round(float(np.min(ious)), 6),
-                }
-                what = f"{n_s} of the {batch_size} images, full pipeline"
-            else:
-                probs_g = last["out"].cpu().numpy()
-                off = np.cumsum([0] + [x.shape[0] for x, _, _ in host_graphs])
-                orc.resgcn_forward(sd, HIDDEN, LAYERS, *host_graphs[0])          # warm
-                t1 = time.perf_counter()
-                ref = [orc.resgcn_forward(sd, HIDDEN, LAYERS, x, ei, ea) for x, ei, ea in host_graphs[:n_s]]
-                dt = time.perf_counter() - t1
-                parity = {"sample": n_s, "max_abs_dprob": max(float(np.abs(probs_g[off[i]:off[i + 1]] - ref[i][1]).max())
-                                                              for i in range(n_s))}
-                what = f"{n_s} of the {batch_size} graphs, GCN forward only"
-            cpu = {"value": round(n_s / dt, 3), "unit": "images/s", "cores": 1, "kind": "port",
-                   "sample": f"{what}; C oracle, 1 thread; host has {len(os.sched_getaffinity(0))} cores"}
+        pipeline_roofline = stage_table = trimap_hist = None
+        if args.workload == "full":
+            # ---- the whole path against the HBM roofline (north star: "as fraction of the HBM roofline")
+            per_img = path_bytes_per_image(H * W, n_nodes / batch_size, n_edges / batch_size)
+            total_b = sum(per_img.values())
+            step_s = elapsed / args.steps
+            pipeline_roofline = {
+                "bound": "hbm", "algorithmic_mb_per_image": round(total_b / 1e6, 2),
+                "by_stage_mb_per_image": {k: round(v / 1e6, 3) for k, v in per_img.items()},
+                "achieved": round(total_b * batch_size / step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(total_b * batch_size / step_s / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "SURVEY 8(d) compulsory bytes per image x images per step / step time; max-flow sweeps are data dependent and not in the model",
+            }
+            # ---- per stage: launch-stream event time per step, the byte model where SURVEY 8(d) gives one, achieved GB/s
+            p_ = H * W * batch_size
+            model_b = {"gcn_aggregate": b_launch * launches / args.steps if launches else None,
+                       "slic_assign": 10 * 16 * p_, "slic_update": 10 * 16 * p_, "slic_connectivity": 8 * p_,
+                       "graph_stats": 36 * p_, "refine_trimap": 9 * p_, "grabcut_gmm": 5 * 20 * p_,
+                       "grabcut_init_gmm": 11 * 4 * p_, "maxflow_relabel": None, "maxflow_push": None,
+                       "graph_knn": None, "graph_prior": None, "gcn_gemm": None}
+            stage_table = {}
+            for k, ms in stage_ms.items():
+                bts = model_b.get(k)
+                stage_table[k] = {"ms_per_step": ms, "model_mb_per_step": round(bts / 1e6, 1) if bts else None,
+                                  "achieved_gbs": round(bts / (ms / 1e3) / 1e9, 1) if bts and ms > 0 else None}
+            gflop = 2.0 * n_nodes * HIDDEN * HIDDEN * LAYERS / 1e9
+            if "gcn_gemm" in stage_table and stage_ms["gcn_gemm"] > 0:
+                stage_table["gcn_gemm"]["achieved_tflops_f32"] = round(gflop / stage_ms["gcn_gemm"], 1)
+            tri = last["out"]["trimap"]
+            hist = torch.bincount(tri.reshape(-1).to(torch.int64), minlength=4).cpu().numpy()
+            trimap_hist = {name: round(float(hist[i]) / float(hist.sum()), 4)
+                           for i, name in enumerate(("definite_bg", "definite_fg", "probable_bg", "probable_fg"))}
+        job = summarise(records)
+        if world > 1 and job["checked_images"]:
+            parity = {"sample": job["checked_images"], "label_map_exact_pct": job["label_map_exact_pct"],
+                      "trimap_exact_images_pct": job["trimap_exact_pct"], "mask_exact_pct": job["mask_exact_pct"],
+                      "mean_mask_iou": job["mean_mask_iou"], "note": "tallies gathered from every rank's record"}
 
         cfg_name = ("configs[2]: full pipeline (SLIC->graph->ResGCNNet->guided-filter trimap->GrabCut 5 it->clean-up), "
                     f"batch {batch_size} of {W}x{H}, n_segments={N_SEGMENTS}") if args.workload == "full" else \
@@ -328,9 +481,11 @@ def main() -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg_name, "images_per_gpu": batch_size, "nodes": n_nodes,
                        "directed_edges": n_edges, "weights": "seeded random init (torch.manual_seed(0))",
-                       "pipelines": n_pipes, "grabcut_lanes": lanes},
-            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity,
-            "stage_ms_per_step": stage_ms, "overlapped": overlapped,
+                       "pipelines": n_pipes, "grabcut_lanes": lanes,
+                       "inputs": "uint8 batch resident in HBM when the clock starts (h2d_inclusive has the copy inside)"},
+            "roofline": roofline, "pipeline_roofline": pipeline_roofline, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity,
+            "stage_ms_per_step": stage_ms, "stages": stage_table, "trimap_label_fractions": trimap_hist,
+            "h2d_inclusive": h2d, "ranks": job["per_rank"] if world > 1 else None, "overlapped": overlapped,
         }
         print(json.dumps(out_json), flush=True)
     if world > 1:

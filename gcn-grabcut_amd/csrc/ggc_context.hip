@@ -4,7 +4,7 @@
 #include <cstdarg>
 #include <mutex>
 
-static std::string g_create_err;
+static thread_local std::string g_create_err;   // ggc_last_error(NULL) reports the calling thread's failed ggc_ctx_create
 
 namespace ggc {
 

@@ -700,7 +700,8 @@ extern "C" int ggc_graph_count(ggc_ctx* ctx, ggc_stream stream, int B, int H, in
     {
         ProfScope prof(ctx, st, "graph_stats");
         const size_t stats_lds = ((size_t)W * 15 + 2) * sizeof(float);  // 3 label rows, lab, hsv, grad, grad/max, x/W as f32 and f64
-        static std::atomic<int> stats_lds_set{0};
+        static std::atomic<int> stats_lds_dev[64];                      // largest size set so far, per device
+        std::atomic<int>& stats_lds_set = stats_lds_dev[ctx->device & 63];
         if ((int)stats_lds > 48 * 1024 && stats_lds_set.load(std::memory_order_acquire) < (int)stats_lds) {
             GGC_REQUIRE(ctx, stats_lds <= 160 * 1024, GGC_E_UNSUPPORTED, "image width %d too large for the statistics kernel", W);
             GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stats), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <string>
@@ -115,6 +116,14 @@ inline T* scratch_t(ggc_ctx* ctx, int slot, size_t count) {
 }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute applies to the CURRENT device: "already done" is remembered per device (one bit each), because one
+// process may hold contexts on several GPUs (cuda:0 then cuda:1).  Devices beyond 63 simply set the attribute every time.
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool need(int dev) const { return dev < 0 || dev >= 64 || !((mask.load(std::memory_order_acquire) >> dev) & 1ull); }
+    void done(int dev) { if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
 
 struct ProfScope {
     ggc_ctx* ctx; hipStream_t st; hipEvent_t b = nullptr;

@@ -621,13 +621,13 @@ int maxflow_image(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* 
     const int stride = tl.pt_x * tl.pt_y;                 // >= relabel tiles per image
     int32_t* lists = scratch_t<int32_t>(ctx, S_GC_M, (size_t)d.B * stride);
     if (!lists) return GGC_E_OOM;
-    static bool attr_done[64] = {};
-    if (ctx->device < 64 && !attr_done[ctx->device]) {
+    static DeviceOnce attr_done;
+    if (attr_done.need(ctx->device)) {
         GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_image<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)sizeof(ImgLds)));
         GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_image<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)sizeof(ImgLds)));
-        attr_done[ctx->device] = true;
+        attr_done.done(ctx->device);
     }
     static const Sched sc{env_int("GGC_MFI_PASSES0", 12), env_int("GGC_MFI_PASSES", 24), env_int("GGC_MFI_INNER", 8),
                           env_int("GGC_MFI_TAIL_ACTIVE", 256), env_int("GGC_MFI_TAIL_PASSES", 16),

@@ -698,13 +698,13 @@ int maxflow_pool(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* s
     PoolCtl* ctl = reinterpret_cast<PoolCtl*>(blk);
     PoolGlobal* G = reinterpret_cast<PoolGlobal*>(blk + ctl_bytes);
     uint32_t* bms = reinterpret_cast<uint32_t*>(blk + ctl_bytes + g_bytes);
-    static bool attr_done[64] = {};
-    if (ctx->device < 64 && !attr_done[ctx->device]) {
+    static DeviceOnce attr_done;
+    if (attr_done.need(ctx->device)) {
         GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_pool<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(sizeof(WaveLds) * WG_WAVES)));
         GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mf_pool<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(sizeof(WaveLds) * WG_WAVES)));
-        attr_done[ctx->device] = true;
+        attr_done.done(ctx->device);
     }
     static const Sched sc{env_int("GGC_MFP_PASSES0", 6), env_int("GGC_MFP_PASSES", 8), env_int("GGC_MFP_INNER", 8),
                           env_int("GGC_MFP_TAIL_ACTIVE", 256), env_int("GGC_MFP_TAIL_PASSES", 16),

@@ -941,6 +941,9 @@ static int prepare_weights(ggc_ctx* ctx) {
     if (m.dev_ok) return GGC_OK;
     int rc = check_ready(ctx);
     if (rc) return rc;
+    // The device copies are about to be overwritten in place by blocking copies on the null stream, which does not wait for
+    // the (non-blocking) stream a previous forward may still be running on: drain the device first.  Weight changes are rare.
+    GGC_HIP(ctx, hipDeviceSynchronize());
     const int D = m.D, Q = m.Q, C = m.C, n = m.n_layers;
     for (auto& kv : m.host) { rc = upload(ctx, kv.first, kv.second); if (rc) return rc; }
     if ((rc = upload(ctx, "#input_proj.0.weightT", transpose(m.host["input_proj.0.weight"], D, IN_CH)))) return rc;
@@ -974,12 +977,12 @@ static int prepare_weights(ggc_ctx* ctx) {
 
 template <int D, int MODE>
 static int launch_gemm(ggc_ctx* ctx, hipStream_t st, int N, const GemmArgs& a) {
-    static std::atomic<bool> attr_set{false};      // contexts on other host threads (GrabCut lanes use none of this, but be safe)
+    static DeviceOnce attr_set;                    // per device; contexts may live on other host threads
     const size_t lds = (size_t)D * D * sizeof(float);
-    if (!attr_set.load(std::memory_order_acquire) && lds > 48 * 1024) {
+    if (attr_set.need(ctx->device) && lds > 48 * 1024) {
         GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<D, MODE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set.store(true, std::memory_order_release);
+        attr_set.done(ctx->device);
     }
     ProfScope prof(ctx, st, MODE == 0 ? "gcn_gemm" : MODE == 1 ? "sage_gemm" : MODE == 2 ? "head_gemm" : "plain_gemm");
     hipLaunchKernelGGL((k_gemm<D, MODE>), dim3(cdiv(N, 128)), dim3(256), lds, st, N, a);
@@ -991,11 +994,11 @@ template <int D, int MODE, int SW, bool GATED>
 static int launch_aggregate_graph_t(ggc_ctx* ctx, hipStream_t st, int G, const int32_t* node_ptr, const int32_t* pack,
                                     const float* xw, const int32_t* row_ptr, const int32_t* col, const float* dis,
                                     const float* bias, const float* gate, const float* h, float* out) {
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
+    static DeviceOnce attr_set;
+    if (attr_set.need(ctx->device)) {
         GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aggregate_graph<D, MODE, SW, GATED>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, AggGraph<SW>::LDS));
-        attr_set.store(true, std::memory_order_release);
+        attr_set.done(ctx->device);
     }
     hipLaunchKernelGGL((k_aggregate_graph<D, MODE, SW, GATED>), dim3(cdiv(G, 8) * 8 * (D / SW)), dim3(512), AggGraph<SW>::LDS, st,
                        G, node_ptr, xw, row_ptr, col, pack, dis, bias, gate, h, out);
@@ -1399,6 +1402,7 @@ static int prepare_weights_gcnnet(ggc_ctx* ctx) {
     if (m.dev_ok) return GGC_OK;
     int rc = check_ready_gcnnet(ctx);
     if (rc) return rc;
+    GGC_HIP(ctx, hipDeviceSynchronize());                  // (see prepare_weights)
     const int D = m.D, n = m.n_layers;
     for (auto& kv : m.host) { if ((rc = upload(ctx, m, kv.first, kv.second))) return rc; }
     if ((rc = upload(ctx, m, "#input_proj.0.weightT", transpose(m.host["input_proj.0.weight"], D, IN_CH)))) return rc;
@@ -1707,11 +1711,11 @@ static int launch_edge_gate(ggc_ctx* ctx, hipStream_t st, int N, const int32_t* 
                             const float* edge_attr, const float* w1T, const float* b1, const float* w2p, const float* b2,
                             const float* conv, const BnW& bn, const float* h, float* out) {
     const size_t lds = ((size_t)D * D + (size_t)EDGE_CH * D + D + (size_t)EG_WAVES * 32 * EG_STAGE) * sizeof(float);
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
+    static DeviceOnce attr_set;
+    if (attr_set.need(ctx->device)) {
         GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gn_edge_gate<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
-        attr_set.store(true, std::memory_order_release);
+        attr_set.done(ctx->device);
     }
     ProfScope prof(ctx, st, "gcnnet_edge_gate");
     hipLaunchKernelGGL((k_gn_edge_gate<D>), dim3(cdiv(N, EG_WAVES * EG_NODES)), dim3(64 * EG_WAVES), lds, st, N, row_ptr, eid, csr_dst,

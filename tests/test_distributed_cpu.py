@@ -1,6 +1,6 @@
-"""CPU test of the N>1 layout with world_size 2 over gloo: contiguous image shards per rank, no data-path
-collective, only the timing / parity records are gathered.  The per-rank "work" is the
-CPU oracle on tiny images so the test needs no GPU."""
+"""CPU test of the N>1 layout with world_size 2 over gloo, driving the PRODUCT's sharding rule and record gather
+(gcn_grabcut/distributed.py, used by bench.py): contiguous image shards per rank, no data-path collective, one all-gather of
+the 64-byte per-rank record.  The per-rank "work" is the CPU oracle on tiny images so the test needs no GPU."""
 import os
 import socket
 import sys
@@ -8,17 +8,10 @@ from pathlib import Path
 
 import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
-
-
-def shard(n_images: int, rank: int, world: int) -> range:
-    """images [rank*per, (rank+1)*per) — the same rule bench.py uses (first_index = rank * batch)."""
-    per = n_images // world
-    return range(rank * per, (rank + 1) * per)
 
 
 def _worker(rank: int, world: int, port: int, out_dir: str):
@@ -26,24 +19,25 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
         sys.path.insert(0, str(p))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gcn_grabcut.distributed import RankRecord, gather_records, shard_range, summarise
     from gcn_grabcut.synthetic import synthetic_image
     from oracle import oracle as orc
-    mine = shard(8, rank, world)
-    fg = []
+    mine = shard_range(9, rank, world)                    # 9 images over 2 ranks: 5 + 4
+    n_regions = 0
     for i in mine:
         img = synthetic_image(24, 32, 40_000 + i)
         lab, hsv, gray, grad = orc.preprocess(img)
         seg, n = orc.slic(lab, 12)
-        fg.append(float(n))
+        n_regions += int(n)
     dist.barrier()
-    rec = torch.tensor([len(mine), 0.25 * (rank + 1), sum(fg)], dtype=torch.float64)   # n_images, seconds, checksum
-    gathered = [torch.zeros_like(rec) for _ in range(world)]
-    dist.all_gather(gathered, rec)
-    t = torch.tensor([rec[1].item()], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rec = RankRecord(n_images=len(mine), seconds=0.25 * (rank + 1), sum_iou=0.9 * len(mine), n_iou=len(mine),
+                     n_trimap_exact=len(mine) - rank, n_label_exact=len(mine), n_mask_exact=len(mine), n_checked=len(mine))
+    records = gather_records(rec)                         # the call bench.py makes after its timed region
+    s = summarise(records)
     if rank == 0:
-        np.save(os.path.join(out_dir, "gathered.npy"), torch.stack(gathered).numpy())
-        np.save(os.path.join(out_dir, "tmax.npy"), t.numpy())
+        np.save(os.path.join(out_dir, "summary.npy"), np.array([s["n_images"], s["seconds_max_over_ranks"], s["images_per_s"],
+                                                                 s["mean_mask_iou"], s["trimap_exact_pct"], s["label_map_exact_pct"],
+                                                                 len(records), records[1].n_images]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,11 +47,22 @@ def test_two_rank_sharding_and_gather(tmp_path, oracle):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    g = np.load(tmp_path / "gathered.npy")
-    assert g.shape == (2, 3)
-    assert g[:, 0].sum() == 8                                  # every image processed exactly once
-    assert np.load(tmp_path / "tmax.npy")[0] == pytest.approx(0.5)   # step time = max over ranks
-    # shards are disjoint, contiguous and cover the list
-    assert sorted(list(shard(8, 0, 2)) + list(shard(8, 1, 2))) == list(range(8))
-    # throughput = all images / slowest rank
-    assert g[:, 0].sum() / 0.5 == pytest.approx(16.0)
+    n, tmax, ips, iou, tri, lab, n_rec, n1 = np.load(tmp_path / "summary.npy")
+    assert n == 9 and n_rec == 2 and n1 == 4              # every image processed exactly once, records in rank order
+    assert tmax == pytest.approx(0.5)                     # step time = max over ranks
+    assert ips == pytest.approx(18.0)                     # throughput = all images / slowest rank
+    assert iou == pytest.approx(0.9) and lab == pytest.approx(100.0)
+    assert tri == pytest.approx(100.0 * 8 / 9)            # rank 1 reported one inexact trimap
+
+
+def test_shard_rule():
+    from gcn_grabcut.distributed import RankRecord, gather_records, shard_range, summarise
+    for n, w in ((2048, 8), (512, 8), (9, 2), (5, 8), (0, 3)):
+        blocks = [list(shard_range(n, r, w)) for r in range(w)]
+        assert sum(blocks, []) == list(range(n))          # disjoint, contiguous, in order, complete
+        assert max(map(len, blocks)) - min(map(len, blocks)) <= 1
+    assert list(shard_range(2048, 3, 8)) == list(range(768, 1024))      # configs[3]: 256 images per GPU
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+    one = gather_records(RankRecord(n_images=4, seconds=2.0))            # no process group: a job of one
+    assert len(one) == 1 and summarise(one)["images_per_s"] == 2.0 and summarise(one)["mean_mask_iou"] is None
