@@ -36,8 +36,10 @@ struct MfTiles { int rt_x, rt_y, pt_x, pt_y; };    // tiles per image
 // One workgroup per image runs the whole max-flow (every round of global relabel + push sweeps) in a single launch.
 // Returns GGC_E_UNSUPPORTED without touching anything when the image has more tiles than the kernel's LDS bitmap holds.
 bool maxflow_image_fits(const GcDims& d);
+// push_passes > 0: ONE push phase only (that many passes of push_inner sweeps per tile visit) on the labels in dist, which
+// must be this round's exact distances; the caller relabels afterwards.  0: the whole max-flow.
 int maxflow_image(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
-                  int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* err_flag);
+                  int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* err_flag, int push_passes = 0, int push_inner = 0);
 // One launch per max-flow, a pool of resident waves over per-image task lists (ggc_maxflow_pool.hip).  rmask must hold the
 // arc masks of rc on entry (k_build_graph writes them).
 bool maxflow_pool_fits(const GcDims& d);

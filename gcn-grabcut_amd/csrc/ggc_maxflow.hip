@@ -506,6 +506,23 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             // few active pixels: their labels stay exact, so more (cheap) launches beat another global relabel
             // first round: labels go stale fastest while most excess is still moving, an early relabel pays (12 vs 24: +3 %)
             const bool tail = total_active <= tail_active;
+            // Tail rounds are chains of up to 64 dependent launches over a few tiles: latency, not work.  The open images are
+            // independent, so ONE launch with a resident workgroup per open image runs the whole push phase instead
+            // (ggc_maxflow_image.hip, push-only mode); the relabel stays here, on the batch-wide work lists.
+            // Measured (tools/mft_sweep.sh, batch 256, 4 lanes): 82.7 ms per GrabCut stage against 76.1 for the launch chains —
+            // the resident workgroups (150 KB of LDS each) keep the other lanes' kernels off their CUs, and the chains of one
+            // lane are what the other three lanes fill.  Off unless GGC_MF_IMAGE_TAIL=1.
+            static const int img_tail = std::getenv("GGC_MF_IMAGE_TAIL") ? env_int("GGC_MF_IMAGE_TAIL", 2) : 2;
+            static const int img_tail_passes = env_int("GGC_MF_IMAGE_TAIL_PASSES", 16), img_tail_inner = env_int("GGC_MF_IMAGE_TAIL_INNER", 32);
+            if (tail && img_tail == 1 && err_flag && maxflow_image_fits(d)) {
+                int32_t* st2 = scratch_t<int32_t>(ctx, S_GC_H, (size_t)B);
+                if (!st2) return GGC_E_OOM;
+                GGC_HIP(ctx, hipMemsetAsync(st2, 0xff, sizeof(int32_t) * B, st));
+                hipLaunchKernelGGL(k_open_state, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, B, n_cur, list_cur, st2);
+                GGC_LAUNCH_CHECK(ctx);
+                if ((rcode = maxflow_image(ctx, st, d, st2, rc, ex, snk, dist, rmask, err_flag, img_tail_passes, img_tail_inner))) return rcode;
+                continue;
+            }
             const int launches = tail ? tail_launch : (round == 0 ? n_launch0 : n_launch);
             // sweeps per visit: measured flat from 6 to 12 and worse either side, in the tail too (32 sweeps: -7 % end to
             // end; a pixel whose admissible arcs saturate keeps the loop alive by relabelling one step per sweep)

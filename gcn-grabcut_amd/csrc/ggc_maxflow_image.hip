@@ -37,7 +37,7 @@ constexpr int RT_PX = RT * RT / 64;                  // pixels per lane in a rel
 constexpr int PT_PX = PT_N / 64;                     // pixels per lane in a push tile (4)
 constexpr int RT_HALO = (RT + 2) * (RT + 2), PT_HALO = (PT_H + 2) * (PT_W + 2);
 
-struct Sched { int passes0, passes, inner, tail_active, tail_passes, tail_inner, max_rounds; };
+struct Sched { int passes0, passes, inner, tail_active, tail_passes, tail_inner, max_rounds, push_only; };   // push_only: one push phase on the labels it is given
 
 struct PushLds { int ex[PT_N]; int sk[PT_N]; int d[PT_H + 2][PT_W + 2]; int rc[8][PT_N]; unsigned short act[PT_N]; };
 struct RelaxLds { int d[RT + 2][RT + 2]; uint32_t m[RT][RT / 4]; int o[RT][RT]; };
@@ -539,9 +539,12 @@ __global__ void __launch_bounds__(MT) k_mf_image(GcDims d, MfTiles tl, Sched sc,
     for (; round < sc.max_rounds; ++round) {
         // ---- global relabel: exact distances to the sink in the residual graph
         MFI_TICK();
-        relabel_init(d, tl, base, snk, dist, L.bm, tid);
-        __syncthreads();
-        int n = compact(L, rt_words, list, tid);
+        int n = 0;
+        if (!sc.push_only) {
+            relabel_init(d, tl, base, snk, dist, L.bm, tid);
+            __syncthreads();
+            n = compact(L, rt_words, list, tid);
+        }
         MFI_TOCK(t_init);
         MFI_TICK();
         while (n > 0) {
@@ -569,7 +572,7 @@ __global__ void __launch_bounds__(MT) k_mf_image(GcDims d, MfTiles tl, Sched sc,
         if (active == 0) { converged = true; break; }
         MFI_TICK();
         // ---- push-relabel sweeps; few active pixels: their labels stay exact, so more (cheap) passes beat another global relabel
-        const bool tail = active <= sc.tail_active;
+        const bool tail = sc.push_only || active <= sc.tail_active;
         const int passes = tail ? sc.tail_passes : (round == 0 ? sc.passes0 : sc.passes);
         const int inner = tail ? sc.tail_inner : sc.inner;
         for (int pass = 0; pass < passes && n > 0; ++pass) {
@@ -582,6 +585,7 @@ __global__ void __launch_bounds__(MT) k_mf_image(GcDims d, MfTiles tl, Sched sc,
             n = compact(L, pt_words, list, tid);
         }
         MFI_TOCK(t_push);
+        if (sc.push_only) { converged = true; break; }      // the caller relabels
     }
     if (!converged && tid == 0) atomicOr(err_flag, 1);
     if (stats) {
@@ -615,7 +619,7 @@ bool maxflow_image_fits(const GcDims& d) {
 }
 
 int maxflow_image(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
-                  int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* err_flag) {
+                  int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* err_flag, int push_passes, int push_inner) {
     if (!maxflow_image_fits(d)) return set_err(ctx, GGC_E_UNSUPPORTED, "image has more push tiles than the per-image kernel's bitmap");
     const MfTiles tl{cdiv(d.W, RT), cdiv(d.H, RT), cdiv(d.W, PT_W), cdiv(d.H, PT_H)};
     const int stride = tl.pt_x * tl.pt_y;                 // >= relabel tiles per image
@@ -629,9 +633,11 @@ int maxflow_image(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* 
                                          (int)sizeof(ImgLds)));
         attr_done.done(ctx->device);
     }
-    static const Sched sc{env_int("GGC_MFI_PASSES0", 12), env_int("GGC_MFI_PASSES", 24), env_int("GGC_MFI_INNER", 8),
-                          env_int("GGC_MFI_TAIL_ACTIVE", 256), env_int("GGC_MFI_TAIL_PASSES", 16),
-                          env_int("GGC_MFI_TAIL_INNER", 32), 4096};
+    static const Sched sc_full{env_int("GGC_MFI_PASSES0", 12), env_int("GGC_MFI_PASSES", 24), env_int("GGC_MFI_INNER", 8),
+                               env_int("GGC_MFI_TAIL_ACTIVE", 256), env_int("GGC_MFI_TAIL_PASSES", 16),
+                               env_int("GGC_MFI_TAIL_INNER", 32), 4096, 0};
+    Sched sc = sc_full;
+    if (push_passes > 0) { sc.push_only = 1; sc.tail_passes = push_passes; sc.tail_inner = push_inner; }
     int32_t* stats = nullptr;
     static const bool trace = std::getenv("GGC_MF_TRACE") != nullptr;
     if (trace) {
