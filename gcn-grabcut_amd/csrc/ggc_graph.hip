@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(256) k_contrast(GDims d, const int32_t* __rest
         const float cd = sqrtf((dx * dx + dy * dy) + dz * dz);
         const float a = si.pcy - s[j].pcy, c = si.pcx - s[j].pcx;
         const float sd = sqrtf(a * a + c * c);
-        acc += (cd * expf(-(sd * sd) / two_cs2)) * (s[j].cnt / csum);
+        acc += (cd * ggc_expf(-(sd * sd) / two_cs2)) * (s[j].cnt / csum);
     }
     acc = wave_sum(acc);
     if (lane == 0) contrast[(size_t)b * d.Nmax + i] = acc;
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(256) k_prior(GDims d, const int32_t* __restric
     for (int i = tid; i < N; i += 256) {
         const float a = s[i].pcy - 0.5f, c = s[i].pcx - 0.5f;
         const float dd = sqrtf(a * a + c * c);
-        fg[i] = unit_apply(ct[i], mn, mx) * expf(-(dd * dd) / two_ce2);
+        fg[i] = unit_apply(ct[i], mn, mx) * ggc_expf(-(dd * dd) / two_ce2);
     }
     __syncthreads();
     block_minmax(N, [&](int i) { return fg[i]; }, mn, mx, sa, sb);
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256) k_prior(GDims d, const int32_t* __restric
         if (bsum > 0.0f) {
             const float d0 = s[i].mlab[0] - mu0, d1 = s[i].mlab[1] - mu1, d2 = s[i].mlab[2] - mu2;
             const float dd = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
-            v = expf(-(dd * dd) / den);
+            v = ggc_expf(-(dd * dd) / den);
         }
         float r = (s[i].border / s[i].safe) * 4.0f;
         r = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "../../include/ggc.h"
+#include "../../include/ggc_fmath.h"
 
 namespace ggc {
 
@@ -152,45 +153,46 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-// GELU(x) = x * Phi(x) (exact, erf-based form; reference model.py uses nn.GELU()).  The aggregation
-// epilogue is VALU-bound with libm's branchy erff (~100 instructions per value), so Phi comes from a
-// branch-free fit of our own: with t = |x| / sqrt(2), u = 1 / (1 + p t),
-//     erfc(t) ~= (a1 u + ... + a6 u^6) exp(-t^2),   |error| < 8e-9 on [0, 6.5]
-// (Lawson-weighted least squares against scipy.special.erfc; p = 0.39030933).  In f32 the absolute
-// error of GELU is 3.8e-7 on [-12, 12], the same as 0.5 x (1 + erff(x / sqrt 2)) evaluated in f32.
-__device__ __forceinline__ float gelu_f(float x) {
-    const float u = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x), 0.27599036693573f, 1.0f));
-    float q = -0.11346635967493057f;                       // a_k / 2, highest power first
-    q = __builtin_fmaf(q, u, 0.44092419743537903f);
-    q = __builtin_fmaf(q, u, -0.3140281140804291f);
-    q = __builtin_fmaf(q, u, 0.3222678005695343f);
-    q = __builtin_fmaf(q, u, 0.04667610302567482f);
-    q = __builtin_fmaf(q, u, 0.1176263764500618f);
-    const float hq = (q * u) * __builtin_amdgcn_exp2f((x * x) * -0.7213475108146667f);   // erfc(|x|/sqrt 2) / 2
-    return x * (x >= 0.0f ? 1.0f - hq : hq);
-}
-// Four values at once on the packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32): same arithmetic as gelu_f.
+// exp / sigmoid / GELU of the networks: the fixed IEEE sequences of include/ggc_fmath.h, shared with the CPU oracle, so that
+// the probabilities — and with them the trimap and the mask — come out bit-identical on both sides (libm, ocml and the
+// hardware's v_exp_f32 / v_rcp_f32 each differ in the last ulp).  GELU(x) = x Phi(x) through an erfc fit, |error| 4e-7.
+__device__ __forceinline__ float gelu_f(float x) { return ggc_geluf(x); }
+__device__ __forceinline__ float sigmoid_f(float x) { return ggc_sigmoidf(x); }
+// Four values at once: the polynomial parts on the packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32 are per-component IEEE
+// operations), the divide and the exponent moves per component.  Same arithmetic as gelu_f, value for value.
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f exp4_f(v4f x) {
+    x = __builtin_elementwise_min(__builtin_elementwise_max(x, (v4f)-87.0f), (v4f)87.0f);
+    const v4f n = __builtin_elementwise_rint(x * 1.44269504088896341f);
+    v4f r = __builtin_elementwise_fma(n, (v4f)-0.693145751953125f, x);
+    r = __builtin_elementwise_fma(n, (v4f)-1.42860682030941723212e-6f, r);
+    v4f p = 1.3888889225e-3f;
+    p = __builtin_elementwise_fma(p, r, (v4f)8.3333337680e-3f);
+    p = __builtin_elementwise_fma(p, r, (v4f)4.1666667908e-2f);
+    p = __builtin_elementwise_fma(p, r, (v4f)1.6666667163e-1f);
+    p = __builtin_elementwise_fma(p, r, (v4f)0.5f);
+    p = __builtin_elementwise_fma(p, r, (v4f)1.0f);
+    p = __builtin_elementwise_fma(p, r, (v4f)1.0f);
+    const v4i e = (__builtin_convertvector(n, v4i) + 127) << 23;
+    return p * __builtin_bit_cast(v4f, e);
+}
 __device__ __forceinline__ v4f gelu4_f(v4f x) {
     const v4f d = __builtin_elementwise_fma(__builtin_elementwise_abs(x), (v4f)0.27599036693573f, (v4f)1.0f);
     v4f u;
-    u.x = __builtin_amdgcn_rcpf(d.x); u.y = __builtin_amdgcn_rcpf(d.y); u.z = __builtin_amdgcn_rcpf(d.z); u.w = __builtin_amdgcn_rcpf(d.w);
+    u.x = 1.0f / d.x; u.y = 1.0f / d.y; u.z = 1.0f / d.z; u.w = 1.0f / d.w;
     v4f q = -0.11346635967493057f;
     q = __builtin_elementwise_fma(q, u, (v4f)0.44092419743537903f);
     q = __builtin_elementwise_fma(q, u, (v4f)-0.3140281140804291f);
     q = __builtin_elementwise_fma(q, u, (v4f)0.3222678005695343f);
     q = __builtin_elementwise_fma(q, u, (v4f)0.04667610302567482f);
     q = __builtin_elementwise_fma(q, u, (v4f)0.1176263764500618f);
-    const v4f t = (x * x) * -0.7213475108146667f;
-    v4f e;
-    e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y); e.z = __builtin_amdgcn_exp2f(t.z); e.w = __builtin_amdgcn_exp2f(t.w);
-    const v4f hq = (q * u) * e, om = 1.0f - hq;
+    const v4f hq = (q * u) * exp4_f((x * x) * -0.5f), om = 1.0f - hq;
     v4f phi;
     phi.x = x.x >= 0.0f ? om.x : hq.x; phi.y = x.y >= 0.0f ? om.y : hq.y;
     phi.z = x.z >= 0.0f ? om.z : hq.z; phi.w = x.w >= 0.0f ? om.w : hq.w;
     return x * phi;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // XCD-aware block remap: blocks b and b+8 share an XCD (observed round-robin
 // placement; speed only).  Maps the hardware block id to a logical id so that

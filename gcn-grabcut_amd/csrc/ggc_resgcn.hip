@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
                 if (g.out) { g.out[(size_t)grow * 3 + 0] = l0; g.out[(size_t)grow * 3 + 1] = l1; g.out[(size_t)grow * 3 + 2] = l2; }
                 if (g.out2) {
                     const float mx = fmaxf(l0, fmaxf(l1, l2));
-                    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
+                    const float e0 = ggc_expf(l0 - mx), e1 = ggc_expf(l1 - mx), e2 = ggc_expf(l2 - mx);
                     const float s = (e0 + e1) + e2;
                     g.out2[(size_t)grow * 3 + 0] = e0 / s; g.out2[(size_t)grow * 3 + 1] = e1 / s; g.out2[(size_t)grow * 3 + 2] = e2 / s;
                 }
@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(256) k_graph_ctx(const int32_t* __restrict__ n
     m = red[0];
     __syncthreads();
     float s = 0.0f;
-    for (int i = beg + tid; i < end; i += 256) s += expf(score[i] - m);
+    for (int i = beg + tid; i < end; i += 256) s += ggc_expf(score[i] - m);
     red[tid] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(256) k_graph_ctx(const int32_t* __restrict__ n
     const int d = tid % D, grp = tid / D;
     float acc = 0.0f;
     if (grp < NG)
-        for (int i = beg + grp; i < end; i += NG) acc += (expf(score[i] - m) / tot) * hjk[(size_t)i * D + d];
+        for (int i = beg + grp; i < end; i += NG) acc += (ggc_expf(score[i] - m) / tot) * hjk[(size_t)i * D + d];
     red[tid] = (grp < NG) ? acc : 0.0f;
     __syncthreads();
     if (tid < D) {
@@ -965,7 +965,7 @@ static int prepare_weights(ggc_ctx* ctx) {
         float mx = jl[0];
         for (float v : jl) mx = v > mx ? v : mx;
         float s = 0.0f;
-        for (size_t k = 0; k < jl.size(); ++k) { w[k] = expf(jl[k] - mx); s += w[k]; }
+        for (size_t k = 0; k < jl.size(); ++k) { w[k] = ggc_expf(jl[k] - mx); s += w[k]; }
         for (size_t k = 0; k < jl.size(); ++k) w[k] = w[k] / s;
         if ((rc = upload(ctx, "#jk_w", w))) return rc;
     }
@@ -1354,7 +1354,7 @@ __global__ void __launch_bounds__(256) k_gn_head(int N, const float* __restrict_
             if (logits) { logits[(size_t)node * 3 + 0] = l0; logits[(size_t)node * 3 + 1] = l1; logits[(size_t)node * 3 + 2] = l2; }
             if (probs) {
                 const float mx = fmaxf(l0, fmaxf(l1, l2));
-                const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
+                const float e0 = ggc_expf(l0 - mx), e1 = ggc_expf(l1 - mx), e2 = ggc_expf(l2 - mx);
                 const float s = (e0 + e1) + e2;
                 probs[(size_t)node * 3 + 0] = e0 / s; probs[(size_t)node * 3 + 1] = e1 / s; probs[(size_t)node * 3 + 2] = e2 / s;
             }

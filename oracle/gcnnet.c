@@ -17,6 +17,7 @@
  *         head.4.{weight[D/2,D],bias[D/2]}   head.6.{weight[3,D/2],bias[3]}
  */
 #include "ggc_oracle.h"
+#include "../include/ggc_fmath.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -27,7 +28,7 @@
 
 int ggo_gcnnet_n_params(int n_layers) { return 10 + 10 * n_layers + 10; }
 
-static float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+static float sigmoid_f(float x) { return ggc_sigmoidf(x); }   /* include/ggc_fmath.h: the sequence the kernels use */
 static float bn_f(float x, const float* w, const float* b, const float* m, const float* v, int k) {
     return (x - m[k]) / sqrtf(v[k] + 1e-5f) * w[k] + b[k];
 }
@@ -108,7 +109,7 @@ int ggo_gcnnet_forward(const float* const* P, int D, int n_layers, int N, int E,
             if (logits) for (int c = 0; c < N_CLS; ++c) logits[(size_t)i * N_CLS + c] = lg[c];
             if (probs) {
                 const float mx = fmaxf(lg[0], fmaxf(lg[1], lg[2]));
-                const float e0 = expf(lg[0] - mx), e1v = expf(lg[1] - mx), e2v = expf(lg[2] - mx);
+                const float e0 = ggc_expf(lg[0] - mx), e1v = ggc_expf(lg[1] - mx), e2v = ggc_expf(lg[2] - mx);
                 const float s = (e0 + e1v) + e2v;
                 probs[(size_t)i * N_CLS + 0] = e0 / s; probs[(size_t)i * N_CLS + 1] = e1v / s; probs[(size_t)i * N_CLS + 2] = e2v / s;
             }

@@ -15,6 +15,7 @@
  * lowest index" (SURVEY hard part 6).
  */
 #include "ggc_oracle.h"
+#include "../include/ggc_fmath.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -134,21 +135,36 @@ void ggo_auto_prior_sigmas(int H, int W, const int32_t* seg, const float* lab, i
         ce[2 * i + 0] = (float)(acc[6 * i + 4] / (double)safe[i]);
         ce[2 * i + 1] = (float)(acc[6 * i + 5] / (double)safe[i]);
     }
+    /* Summation orders.  The reference sums with numpy (pairwise float32 sums); a float sum has no canonical order, and the
+     * restatement fixes THE ORDER OF THE MI355X KERNELS (k_contrast / k_prior in csrc/ggc_graph.hip), so that the two produce
+     * the same bits and a trimap can be compared pixel for pixel end to end: a lane (of 64) or a thread (of 256) sums every
+     * 64th / 256th term in index order, then the partial sums are combined by the butterfly / halving tree written out below.
+     * exp is the fixed IEEE sequence of include/ggc_fmath.h on both sides.  Against the reference's own output the result
+     * stays within 2e-5 (tests/test_graph_oracle.py). */
     /* cue 1: spatially weighted global colour contrast */
-    float csum = pairwise_f32(counts, N);
+    float csum = (float)((double)H * (double)W);          /* counts.sum(): exact in float32 below 2^24 pixels */
     if (!(csum > 1.0f)) csum = 1.0f;
     float* contrast = (float*)malloc((size_t)N * sizeof(float));
-    float* row = (float*)malloc((size_t)N * sizeof(float));
+    float* row = NULL;
     const float two_cs2 = (float)(2 * contrast_sigma * contrast_sigma);   /* python float, then a float32 operand */
     for (int i = 0; i < N; ++i) {
-        for (int j = 0; j < N; ++j) {
-            const float cd = norm3(ml + 3 * i, ml + 3 * j);
-            const float a = ce[2 * i] - ce[2 * j], b = ce[2 * i + 1] - ce[2 * j + 1];
-            const float sd = sqrtf(a * a + b * b);
-            const float sw = expf(-(sd * sd) / two_cs2);
-            row[j] = (cd * sw) * (counts[j] / csum);
+        float lane[64];
+        for (int l = 0; l < 64; ++l) {
+            float acc = 0.0f;
+            for (int j = l; j < N; j += 64) {
+                const float cd = norm3(ml + 3 * i, ml + 3 * j);
+                const float a = ce[2 * i] - ce[2 * j], b = ce[2 * i + 1] - ce[2 * j + 1];
+                const float sd = sqrtf(a * a + b * b);
+                acc += (cd * ggc_expf(-(sd * sd) / two_cs2)) * (counts[j] / csum);
+            }
+            lane[l] = acc;
         }
-        contrast[i] = pairwise_f32(row, N);
+        for (int o = 32; o > 0; o >>= 1) {                 /* wave butterfly: every lane ends with the same sum */
+            float t[64];
+            for (int l = 0; l < 64; ++l) t[l] = lane[l] + lane[l ^ o];
+            memcpy(lane, t, sizeof t);
+        }
+        contrast[i] = lane[0];
     }
     unit_norm(contrast, N);
     const float two_ce2 = (float)(2 * centre_sigma * centre_sigma);
@@ -156,7 +172,7 @@ void ggo_auto_prior_sigmas(int H, int W, const int32_t* seg, const float* lab, i
     for (int i = 0; i < N; ++i) {
         const float a = ce[2 * i] - 0.5f, b = ce[2 * i + 1] - 0.5f;
         const float d = sqrtf(a * a + b * b);
-        fg[i] = contrast[i] * expf(-(d * d) / two_ce2);
+        fg[i] = contrast[i] * ggc_expf(-(d * d) / two_ce2);
     }
     unit_norm(fg, N);
     /* cue 2: background model from the image frame */
@@ -165,28 +181,45 @@ void ggo_auto_prior_sigmas(int H, int W, const int32_t* seg, const float* lab, i
     for (int x = 0; x < W; ++x) { bc[seg[(size_t)(H - 1) * W + x]] += 1.0f; }
     for (int y = 0; y < H; ++y) { bc[seg[(size_t)y * W]] += 1.0f; }
     for (int y = 0; y < H; ++y) { bc[seg[(size_t)y * W + W - 1]] += 1.0f; }
-    const float bsum = pairwise_f32(bc, N);
     float* bg = (float*)calloc((size_t)N, sizeof(float));
-    if (bsum > 0.0f) {
-        float mu[3] = {0, 0, 0};
-        for (int i = 0; i < N; ++i) { const float w = bc[i] / bsum; for (int c = 0; c < 3; ++c) mu[c] += ml[3 * i + c] * w; }
-        float var[3] = {0, 0, 0};
-        for (int i = 0; i < N; ++i) {
-            const float w = bc[i] / bsum;
-            for (int c = 0; c < 3; ++c) { const float d = ml[3 * i + c] - mu[c]; var[c] += (d * d) * w; }
+    {
+        /* weighted mean / variance of the frame regions' colours: double partial sums of 256 strided threads, halving tree */
+        double ds[4][256];
+        for (int t = 0; t < 256; ++t) {
+            double bs = 0, m0 = 0, m1 = 0, m2 = 0;
+            for (int i = t; i < N; i += 256) {
+                const double w = (double)bc[i];
+                bs += w; m0 += w * (double)ml[3 * i]; m1 += w * (double)ml[3 * i + 1]; m2 += w * (double)ml[3 * i + 2];
+            }
+            ds[0][t] = bs; ds[1][t] = m0; ds[2][t] = m1; ds[3][t] = m2;
         }
-        const float var_bg = (var[0] + var[1]) + var[2];
+        for (int o = 128; o > 0; o >>= 1) for (int t = 0; t < o; ++t) for (int c = 0; c < 4; ++c) ds[c][t] += ds[c][t + o];
+        const float bsum = (float)ds[0][0];
+        const float mu[3] = {(float)(ds[1][0] / ds[0][0]), (float)(ds[2][0] / ds[0][0]), (float)(ds[3][0] / ds[0][0])};
+        for (int t = 0; t < 256; ++t) {
+            double var = 0;
+            for (int i = t; i < N; i += 256) {
+                const float w = bc[i] / bsum;
+                const float d0 = ml[3 * i] - mu[0], d1 = ml[3 * i + 1] - mu[1], d2 = ml[3 * i + 2] - mu[2];
+                var += (double)((d0 * d0) * w) + (double)((d1 * d1) * w) + (double)((d2 * d2) * w);
+            }
+            ds[0][t] = var;
+        }
+        for (int o = 128; o > 0; o >>= 1) for (int t = 0; t < o; ++t) ds[0][t] += ds[0][t + o];
+        const float var_bg = (float)ds[0][0];
         const double sigma_bg = var_bg > 1e-6 ? (double)sqrtf(var_bg) : sqrt(1e-6);
         const float den = (float)(2.0 * (sigma_bg + 1e-6) * (sigma_bg + 1e-6));
         for (int i = 0; i < N; ++i) {
-            const float d = norm3(ml + 3 * i, mu);
-            bg[i] = expf(-(d * d) / den);
+            float v = 0.0f;
+            if (bsum > 0.0f) {
+                const float d0 = ml[3 * i] - mu[0], d1 = ml[3 * i + 1] - mu[1], d2 = ml[3 * i + 2] - mu[2];
+                const float dd = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+                v = ggc_expf(-(dd * dd) / den);
+            }
+            float r = (bc[i] / safe[i]) * 4.0f;
+            r = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
+            bg[i] = (v != v) ? v : (v > r ? v : r);        /* np.maximum propagates NaN */
         }
-    }
-    for (int i = 0; i < N; ++i) {
-        float r = (bc[i] / safe[i]) * 4.0f;
-        r = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
-        if (r > bg[i] || bg[i] != bg[i]) bg[i] = (bg[i] != bg[i]) ? bg[i] : r; /* np.maximum propagates NaN */
     }
     unit_norm(bg, N);
     for (int i = 0; i < N; ++i) {

@@ -1,6 +1,7 @@
 """GPU parity: ResGCNNet forward and the GCNConv scatter-gather through the
-C ABI of libggc_hip.so against the CPU oracle (tolerance from the north star:
-1e-4 on logits; the un-fused aggregation is bit-exact)."""
+C ABI of libggc_hip.so against the CPU oracle.  The north star asks for 1e-4 on logits; the oracle sums in the kernels'
+order (fma chains of the matrix pipe, butterflies of the LayerNorm statistics) with the shared exp / GELU sequences of
+include/ggc_fmath.h, so logits and probabilities are compared for EQUALITY."""
 import numpy as np
 import pytest
 import torch
@@ -8,7 +9,6 @@ import torch
 from helpers import chain_graph, superpixel_like_graph, seeded_state_dict
 
 pytestmark = pytest.mark.gpu
-TOL_LOGITS = 1e-4   # BASELINE.json north_star: "within 1e-4 on GCN logits"
 
 
 def _np_state(sd):
@@ -29,9 +29,9 @@ def test_forward_matches_oracle(oracle, gpu_ctx, hidden, layers, n):
     d = _data(x, ei, ea)
     got = model(d).cpu().numpy()
     assert got.shape == (n, 3)
-    assert np.abs(got - want).max() <= TOL_LOGITS
+    assert np.array_equal(got, want)
     probs = model.predict_probs(d)
-    assert np.abs(probs - want_p).max() <= 1e-5
+    assert np.array_equal(probs, want_p)
     assert np.allclose(probs.sum(1), 1.0, atol=1e-6)
 
 
@@ -58,14 +58,14 @@ def test_batched_equals_single_and_oracle(oracle, gpu_ctx):
     datas = [_data(*g) for g in graphs]
     one = torch.cat([model(d) for d in datas]).cpu().numpy()
     both = model(Batch.from_data_list(datas)).cpu().numpy()
-    assert np.abs(one - both).max() <= TOL_LOGITS
+    assert np.array_equal(one, both)                       # reference tests/test.py:294-306 asks for 1e-4; here: identical
     off = np.cumsum([0] + [g[0].shape[0] for g in graphs])
     want, _ = oracle.resgcn_forward(
         _np_state(sd), 128, 6, np.concatenate([g[0] for g in graphs]),
         np.concatenate([g[1] + off[i] for i, g in enumerate(graphs)], 1),
         np.concatenate([g[2] for g in graphs]),
         np.concatenate([np.full(g[0].shape[0], i) for i, g in enumerate(graphs)]))
-    assert np.abs(both - want).max() <= TOL_LOGITS
+    assert np.array_equal(both, want)
 
 
 def test_reference_chain_graph_shapes(gpu_ctx):
@@ -85,7 +85,7 @@ def test_isolated_node(oracle, gpu_ctx):
     ei, ea = ei[:, keep], ea[keep]
     want, _ = oracle.resgcn_forward(_np_state(sd), 32, 2, x.numpy(), ei.numpy(), ea.numpy())
     got = model(_data(x, ei, ea)).cpu().numpy()
-    assert np.isfinite(got).all() and np.abs(got - want).max() <= TOL_LOGITS
+    assert np.isfinite(got).all() and np.array_equal(got, want)
 
 
 def _hub_graph(n, hub_deg, seed):
@@ -130,14 +130,13 @@ def test_forward_aggregation_routes(oracle, gpu_ctx, case):
     d = _data(x, ei, ea, batch=torch.as_tensor(batch))
     d.num_graphs = int(batch.max()) + 1
     got = model(d).cpu().numpy()
-    assert np.abs(got - want).max() <= TOL_LOGITS
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("d", [32, 64, 96, 128])
 def test_aggregate_bit_exact_and_fused(oracle, gpu_ctx, d):
-    """M3 alone: CSR build + gather. Unfused output is bit-identical to the oracle
-    (same edge order, one rounding per op); the fused GELU epilogue may differ by
-    the erff implementation only."""
+    """M3 alone: CSR build + gather.  Bit-identical to the oracle with and without the fused epilogue (same edge order,
+    one rounding per op, the shared GELU sequence of include/ggc_fmath.h)."""
     from gcn_grabcut import _native
     n = 1203
     x, ei, _ = superpixel_like_graph(n=n, seed=11)
@@ -171,8 +170,7 @@ def test_aggregate_bit_exact_and_fused(oracle, gpu_ctx, d):
     gpu_ctx.call("ggc_gcn_aggregate", st, n, d, xw_d.data_ptr(), row_ptr.data_ptr(), col.data_ptr(), dis.data_ptr(),
                  bias_d.data_ptr(), gate_d.data_ptr(), h_d.data_ptr(), out.data_ptr())
     want = oracle.gcn_aggregate(xw, ei, bias, gate, h)
-    err = float(np.abs(out.cpu().numpy() - want).max())
-    assert err <= 2e-6, err
+    assert np.array_equal(out.cpu().numpy(), want)
 
 
 def test_errors_are_loud(gpu_ctx):
