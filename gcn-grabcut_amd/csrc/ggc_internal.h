@@ -159,12 +159,13 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float gelu_f(float x) { return ggc_geluf(x); }
 __device__ __forceinline__ float sigmoid_f(float x) { return ggc_sigmoidf(x); }
 // Four values at once: the polynomial parts on the packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32 are per-component IEEE
-// operations), the divide and the exponent moves per component.  Same arithmetic as gelu_f, value for value.
+// operations), the exponent moves per component.  Same arithmetic as gelu_f, value for value.
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4f exp4_f(v4f x) {
-    x = __builtin_elementwise_min(__builtin_elementwise_max(x, (v4f)-87.0f), (v4f)87.0f);
-    const v4f n = __builtin_elementwise_rint(x * 1.44269504088896341f);
+__device__ __forceinline__ v4f exp4_nonpos_f(v4f x) {      // ggc_expf for x <= 0 (the upper clamp cannot bind)
+    x = __builtin_elementwise_max(x, (v4f)-87.0f);
+    const v4f z = x * 1.44269504088896341f + 12582912.0f;
+    const v4f n = z - 12582912.0f;
     v4f r = __builtin_elementwise_fma(n, (v4f)-0.693145751953125f, x);
     r = __builtin_elementwise_fma(n, (v4f)-1.42860682030941723212e-6f, r);
     v4f p = 1.3888889225e-3f;
@@ -174,20 +175,23 @@ __device__ __forceinline__ v4f exp4_f(v4f x) {
     p = __builtin_elementwise_fma(p, r, (v4f)0.5f);
     p = __builtin_elementwise_fma(p, r, (v4f)1.0f);
     p = __builtin_elementwise_fma(p, r, (v4f)1.0f);
-    const v4i e = (__builtin_convertvector(n, v4i) + 127) << 23;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const v4u e = (__builtin_bit_cast(v4u, z) << 23) + 0x3F800000u;
     return p * __builtin_bit_cast(v4f, e);
 }
 __device__ __forceinline__ v4f gelu4_f(v4f x) {
     const v4f d = __builtin_elementwise_fma(__builtin_elementwise_abs(x), (v4f)0.27599036693573f, (v4f)1.0f);
-    v4f u;
-    u.x = 1.0f / d.x; u.y = 1.0f / d.y; u.z = 1.0f / d.z; u.w = 1.0f / d.w;
+    v4f u = __builtin_bit_cast(v4f, (v4i)0x7EF311C7 - __builtin_bit_cast(v4i, d));     // ggc_rcp_nr, four at a time
+    u = u * __builtin_elementwise_fma(-d, u, (v4f)2.0f);
+    u = u * __builtin_elementwise_fma(-d, u, (v4f)2.0f);
+    u = u * __builtin_elementwise_fma(-d, u, (v4f)2.0f);
     v4f q = -0.11346635967493057f;
     q = __builtin_elementwise_fma(q, u, (v4f)0.44092419743537903f);
     q = __builtin_elementwise_fma(q, u, (v4f)-0.3140281140804291f);
     q = __builtin_elementwise_fma(q, u, (v4f)0.3222678005695343f);
     q = __builtin_elementwise_fma(q, u, (v4f)0.04667610302567482f);
     q = __builtin_elementwise_fma(q, u, (v4f)0.1176263764500618f);
-    const v4f hq = (q * u) * exp4_f((x * x) * -0.5f), om = 1.0f - hq;
+    const v4f hq = (q * u) * exp4_nonpos_f((x * x) * -0.5f), om = 1.0f - hq;
     v4f phi;
     phi.x = x.x >= 0.0f ? om.x : hq.x; phi.y = x.y >= 0.0f ? om.y : hq.y;
     phi.z = x.z >= 0.0f ? om.z : hq.z; phi.w = x.w >= 0.0f ? om.w : hq.w;
