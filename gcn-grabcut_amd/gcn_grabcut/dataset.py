@@ -18,8 +18,9 @@ Differences that are deliberate and documented:
 * Images are decoded with Pillow (OpenCV is not installed) and resized with a plain
   half-pixel-centre bilinear / nearest filter.  `cv2.imread` / `cv2.resize` parity is
   UNPINNED: neither library nor golden vectors are available here.
-* Seeded augmentation (`aug_seed`) needs OpenCV's warps and colour transforms and is not
-  provided: descriptors with an `aug_seed` raise NotImplementedError.
+* Seeded augmentation (`aug_seed`, reference :107-168) draws its decisions from Python's `random` in the reference's
+  order, so a seed selects the same flips / angles / jitters / crops; the warps and the 8-bit HSV round trip are plain
+  numpy here instead of OpenCV (pixel parity UNPINNED for the same reason).
 
 Training itself (Dataset classes, loaders, samplers) stays out of scope.
 """
@@ -29,6 +30,7 @@ import hashlib
 import logging
 import os
 import time
+import random
 import zlib
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -106,13 +108,109 @@ def _resize_pair(image: np.ndarray, mask: np.ndarray, max_size: int):
     return image, mask
 
 
+# ----------------------------------------------------------------------- augmentation
+# reference dataset.py:107-168: flip, rotation in [-15, 15] degrees (bilinear image / nearest mask, reflected border),
+# brightness / contrast / saturation jitter, crop + resize back.  The random DECISIONS are Python's `random` module drawn in
+# the reference's order, so a descriptor's aug_seed selects the same transforms here as there; the pixel arithmetic of the
+# warps and of the 8-bit HSV round trip is OpenCV's in the reference and plain numpy here (parity with OpenCV unpinned:
+# the library is absent; the formulas follow its documented conventions: pixel-centre bilinear taps, H in [0, 180)).
+def _reflect(i: np.ndarray, n: int) -> np.ndarray:
+    """cv2.BORDER_REFLECT: ... c b a | a b c ... | c b a ..."""
+    if n == 1:
+        return np.zeros_like(i)
+    p = np.mod(i, 2 * n)
+    return np.where(p < n, p, 2 * n - 1 - p)
+
+
+def _warp_affine(img: np.ndarray, m: np.ndarray, linear: bool) -> np.ndarray:
+    """dst(x, y) = src(M^-1 (x, y)) like cv2.warpAffine(img, M, (W, H)) with BORDER_REFLECT."""
+    h, w = img.shape[:2]
+    a = np.vstack([m, [0.0, 0.0, 1.0]])
+    inv = np.linalg.inv(a)
+    xx, yy = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    sx = inv[0, 0] * xx + inv[0, 1] * yy + inv[0, 2]
+    sy = inv[1, 0] * xx + inv[1, 1] * yy + inv[1, 2]
+    if not linear:
+        xi, yi = _reflect(np.rint(sx).astype(np.int64), w), _reflect(np.rint(sy).astype(np.int64), h)
+        return img[yi, xi]
+    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+    fx, fy = (sx - x0), (sy - y0)
+    if img.ndim == 3:
+        fx, fy = fx[..., None], fy[..., None]
+    x0r, x1r, y0r, y1r = _reflect(x0, w), _reflect(x0 + 1, w), _reflect(y0, h), _reflect(y0 + 1, h)
+    f = img.astype(np.float64)
+    top = f[y0r, x0r] * (1 - fx) + f[y0r, x1r] * fx
+    bot = f[y1r, x0r] * (1 - fx) + f[y1r, x1r] * fx
+    return np.clip(np.floor(top * (1 - fy) + bot * fy + 0.5), 0, 255).astype(img.dtype)
+
+
+def _rotation_matrix(cx: float, cy: float, angle_deg: float) -> np.ndarray:
+    """cv2.getRotationMatrix2D(centre, angle, 1.0)"""
+    al, be = np.cos(np.deg2rad(angle_deg)), np.sin(np.deg2rad(angle_deg))
+    return np.array([[al, be, (1 - al) * cx - be * cy], [-be, al, be * cx + (1 - al) * cy]], np.float64)
+
+
+def _bgr_to_hsv8(bgr: np.ndarray) -> np.ndarray:
+    """8-bit HSV in OpenCV's convention: H in [0, 180), S and V in [0, 255]"""
+    f = bgr.astype(np.float64)
+    b, g, r = f[..., 0], f[..., 1], f[..., 2]
+    v = np.maximum(np.maximum(r, g), b)
+    d = v - np.minimum(np.minimum(r, g), b)
+    s = np.where(v > 0, d / np.maximum(v, 1e-12) * 255.0, 0.0)
+    dd = np.maximum(d, 1e-12)
+    hdeg = np.where(v == r, 60.0 * (g - b) / dd, np.where(v == g, 120.0 + 60.0 * (b - r) / dd, 240.0 + 60.0 * (r - g) / dd))
+    hdeg = np.where(d > 0, np.mod(hdeg, 360.0), 0.0)
+    out = np.stack([np.rint(hdeg / 2.0) % 180, np.rint(s), v], -1)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def _hsv8_to_bgr(hsv: np.ndarray) -> np.ndarray:
+    f = hsv.astype(np.float64)
+    hh, s, v = f[..., 0] * 2.0 / 60.0, f[..., 1] / 255.0, f[..., 2]
+    i = np.floor(hh).astype(np.int64) % 6
+    ff = hh - np.floor(hh)
+    p, q, t = v * (1 - s), v * (1 - s * ff), v * (1 - s * (1 - ff))
+    r = np.choose(i, [v, q, p, p, t, v]); g = np.choose(i, [t, v, v, q, p, p]); b = np.choose(i, [p, p, t, v, v, q])
+    return np.clip(np.rint(np.stack([b, g, r], -1)), 0, 255).astype(np.uint8)
+
+
+def _color_jitter(image: np.ndarray) -> np.ndarray:
+    """reference dataset.py:154-168 (three draws: brightness, contrast, saturation)"""
+    img = image.astype(np.float32)
+    img = np.clip(img + np.float32(random.uniform(-40, 40)), 0, 255)
+    img = np.clip(np.float32(128) + np.float32(random.uniform(0.7, 1.3)) * (img - np.float32(128)), 0, 255)
+    hsv = _bgr_to_hsv8(img.astype(np.uint8)).astype(np.float32)
+    hsv[:, :, 1] = np.clip(hsv[:, :, 1] * np.float32(random.uniform(0.7, 1.3)), 0, 255)
+    return _hsv8_to_bgr(hsv.astype(np.uint8))
+
+
+def augment_sample(image: np.ndarray, mask: np.ndarray, prob_flip: float = 0.5, prob_rotate: float = 0.3,
+                   prob_color: float = 0.5, prob_crop: float = 0.3):
+    """Stochastic augmentation of an image / mask pair — reference dataset.py:107-151; draws from `random` in its order."""
+    h, w = image.shape[:2]
+    if random.random() < prob_flip:
+        image, mask = image[:, ::-1], mask[:, ::-1]
+    if random.random() < prob_rotate:
+        m = _rotation_matrix(w / 2, h / 2, random.uniform(-15, 15))
+        image = _warp_affine(image, m, linear=True)
+        mask = _warp_affine(mask.astype(np.uint8), m, linear=False)
+    if random.random() < prob_color:
+        image = _color_jitter(image)
+    if random.random() < prob_crop:
+        scale = random.uniform(0.75, 1.0)
+        ch, cw = int(h * scale), int(w * scale)
+        y0 = random.randint(0, h - ch)
+        x0 = random.randint(0, w - cw)
+        image = _resize_bilinear_u8(image[y0:y0 + ch, x0:x0 + cw], h, w)
+        mask = _resize_nearest(mask[y0:y0 + ch, x0:x0 + cw], h, w)
+    return np.ascontiguousarray(image), np.ascontiguousarray(mask)
+
+
 def materialise(sample: dict) -> Optional[dict]:
     """Descriptor -> {"image": BGR uint8, "gt_mask": uint8 {0,1}, "name"} — reference dataset.py:316-361.
     In-memory samples pass through; unreadable or degenerate pairs give None."""
     if "image" in sample and "gt_mask" in sample:
         return sample
-    if sample.get("aug_seed") is not None:
-        raise NotImplementedError("seeded augmentation needs OpenCV's warps and colour transforms (out of scope here)")
     from PIL import Image
     try:
         with Image.open(sample["image_path"]) as im:
@@ -127,6 +225,13 @@ def materialise(sample: dict) -> Optional[dict]:
         return None
     image, mask = _resize_pair(image, mask, sample.get("max_size", 512))
     gt_mask = (mask > 127).astype(np.uint8)
+    if sample.get("aug_seed") is not None:                 # seeded: the copy is the same every run (dataset.py:343-353)
+        state = random.getstate()
+        random.seed(sample["aug_seed"])
+        try:
+            image, gt_mask = augment_sample(image, gt_mask, prob_flip=0.5, prob_rotate=0.4, prob_color=0.6, prob_crop=0.4)
+        finally:
+            random.setstate(state)
     if gt_mask.sum() < 200 or (1 - gt_mask).sum() < 200:
         return None
     return {"image": np.ascontiguousarray(image), "gt_mask": np.ascontiguousarray(gt_mask), "name": sample.get("name", "")}

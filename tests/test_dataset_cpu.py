@@ -27,8 +27,6 @@ def test_list_pairs_orders_and_seeds(tmp_path):
     # reference dataset.py:303-309: seed + 1000003 * k + crc32(stem) % 100003
     assert out[2]["aug_seed"] == 42 + 1000003 * 1 + zlib.crc32(b"a") % 100003
     assert out[3]["mask_path"].endswith("c.bmp")
-    with pytest.raises(NotImplementedError):
-        ds.materialise(out[1])
 
 
 def test_cache_key_is_the_reference_recipe():
@@ -72,3 +70,46 @@ def test_materialise_decodes_resizes_and_filters(tmp_path):
     _write(tmp_path / "m2.png", np.zeros((100, 160), np.uint8))
     assert ds.materialise({**s, "mask_path": str(tmp_path / "m2.png")}) is None            # degenerate: no foreground
     assert ds.materialise({"image": img, "gt_mask": mask}) is not None                       # in-memory samples pass through
+
+
+def test_seeded_augmentation_follows_the_reference_draw_order(tmp_path):
+    """reference dataset.py:107-168, 343-353: the decisions come from `random` seeded with aug_seed, in the order
+    flip? rotate? [angle] colour? [brightness, contrast, saturation] crop? [scale, y0, x0]; the global RNG state is restored."""
+    import random
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 255, (120, 160, 3), dtype=np.uint8)
+    mask = np.zeros((120, 160), np.uint8); mask[30:90, 40:130] = 255
+    _write(tmp_path / "i.png", img[:, :, ::-1]); _write(tmp_path / "m.png", mask)
+    base = {"image_path": str(tmp_path / "i.png"), "mask_path": str(tmp_path / "m.png"), "max_size": 512, "name": "i"}
+    random.seed(1234)
+    before = random.getstate()
+    a = ds.materialise({**base, "aug_seed": 77})
+    b = ds.materialise({**base, "aug_seed": 77})
+    c = ds.materialise({**base, "aug_seed": 78})
+    assert random.getstate() == before                                     # caller's RNG untouched
+    assert np.array_equal(a["image"], b["image"]) and np.array_equal(a["gt_mask"], b["gt_mask"])     # same seed, same copy
+    assert not np.array_equal(a["image"], c["image"])
+    assert a["image"].shape == img.shape and a["image"].dtype == np.uint8 and set(np.unique(a["gt_mask"])) <= {0, 1}
+    # replay the draw sequence by hand for seed 77 and compare the geometric decisions
+    r = random.Random(77)
+    flip = r.random() < 0.5
+    rot = r.random() < 0.4
+    angle = r.uniform(-15, 15) if rot else None
+    col = r.random() < 0.6
+    if col:
+        [r.uniform(-40, 40), r.uniform(0.7, 1.3), r.uniform(0.7, 1.3)]
+    crop = r.random() < 0.4
+    plain = ds.materialise({**base, "aug_seed": None})
+    if not rot and not crop:                                               # pure flip (+ colour): the mask is the flipped mask
+        want = plain["gt_mask"][:, ::-1] if flip else plain["gt_mask"]
+        assert np.array_equal(a["gt_mask"], want)
+    # the pieces, on their own
+    assert np.array_equal(ds._warp_affine(img, ds._rotation_matrix(80, 60, 0.0), linear=True), img)      # identity warp
+    m90 = ds._rotation_matrix(59.5, 59.5, 90.0)
+    sq = rng.integers(0, 255, (120, 120), dtype=np.uint8)
+    assert np.array_equal(ds._warp_affine(sq, m90, linear=False), np.rot90(sq))                          # cv2: positive angle = counter-clockwise
+    for bgr, hsv in (((0, 0, 255), (0, 255, 255)), ((0, 255, 0), (60, 255, 255)), ((255, 0, 0), (120, 255, 255)), ((128, 128, 128), (0, 0, 128))):
+        px = np.array([[bgr]], np.uint8)
+        assert tuple(ds._bgr_to_hsv8(px)[0, 0]) == hsv and tuple(ds._hsv8_to_bgr(np.array([[hsv]], np.uint8))[0, 0]) == bgr
+    back = ds._hsv8_to_bgr(ds._bgr_to_hsv8(img))
+    assert np.abs(back.astype(int) - img.astype(int)).max() <= 4           # 8-bit round trip (H has 2-degree steps)

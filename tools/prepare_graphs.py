@@ -5,7 +5,7 @@ Build the superpixel graphs of a dataset on the MI355X and store them in the cac
     python3 tools/prepare_graphs.py --images DIR --masks DIR --cache DIR --workers 6 --max-size 384
 
 `--workers` are decode threads; the graphs themselves are built in device batches of `--batch`
-equally sized images.  `--augment` > 0 is refused (needs OpenCV, see gcn_grabcut/dataset.py).
+equally sized images.  `--augment N` adds N seeded augmented copies per image (host-side, see gcn_grabcut/dataset.py).
 """
 from __future__ import annotations
 
@@ -29,7 +29,7 @@ def main() -> None:
     ap.add_argument("--workers", type=int, default=4)
     ap.add_argument("--max-size", type=int, default=384)
     ap.add_argument("--superpixels", type=int, default=300)
-    ap.add_argument("--augment", type=int, default=0, help="Seeded augmented copies per image (not supported: needs OpenCV)")
+    ap.add_argument("--augment", type=int, default=0, help="Seeded augmented copies per image")
     ap.add_argument("--limit", type=int, default=0)
     ap.add_argument("--stride", type=int, default=1, help="Take every n-th sample, to cover a split sparsely")
     ap.add_argument("--seed", type=int, default=42)
@@ -42,7 +42,7 @@ def main() -> None:
         samples = samples[::args.stride]
     if args.limit:
         samples = samples[:args.limit]
-    # results are discarded: the point of the run is the cache it leaves behind
+    # nothing is returned to the caller: the run exists to fill the cache directory
     prepare_dataset(samples, SuperpixelGraphConfig(n_segments=args.superpixels), cache_dir=args.cache,
                     workers=args.workers, keep_segments=False, desc="cache: ", batch_size=args.batch)
 
