@@ -82,6 +82,7 @@ int ggc_ctx_destroy(ggc_ctx* ctx) {
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (auto& kv : ctx->model.dev) if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& kv : ctx->model2.dev) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : ctx->model3.dev) if (kv.second.p) (void)hipFree(kv.second.p);
     delete ctx;
     return GGC_OK;
 }

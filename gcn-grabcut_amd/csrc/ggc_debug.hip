@@ -10,6 +10,8 @@ extern "C" int ggc_debug_read_scratch(ggc_ctx* ctx, const char* name, void* host
         {"slic_image_a", ggc::S_SLIC_IMG}, {"slic_image_b", ggc::S_SLIC_TMP}, {"slic_stale", ggc::S_SLIC_AUX2},
         {"grabcut_comp", ggc::S_GC_D}, {"grabcut_nweights", ggc::S_GC_E}, {"grabcut_gmm", ggc::S_GC_B},
         {"grabcut_excess_sink_dist", ggc::S_GC_G},
+        {"net_states", ggc::S_STATES}, {"net_xw", ggc::S_XW}, {"net_agg", ggc::S_AGG}, {"net_hjk", ggc::S_HJK},
+        {"net_score", ggc::S_SCORE}, {"net_gvec", ggc::S_GVEC}, {"net_gate", ggc::S_GATE},
     };
     for (auto& t : tab)
         if (std::strcmp(t.n, name) == 0) {

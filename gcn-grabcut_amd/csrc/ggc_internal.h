@@ -75,6 +75,7 @@ struct ggc_ctx {
     ggc::Buf slots[ggc::S_COUNT];
     ggc::ResgcnWeights model;
     ggc::ResgcnWeights model2;             // GCNTrimapNet (same container: host copies by key, device copies)
+    ggc::ResgcnWeights model3;             // GATTrimapNet (Q = attention heads)
     ggc::GraphState graph;
     int n_cu = 256;
     float prior_two_ce2 = (float)(2 * 0.45 * 0.45), prior_two_cs2 = (float)(2 * 0.40 * 0.40);   // compute_auto_prior sigmas (reference defaults)

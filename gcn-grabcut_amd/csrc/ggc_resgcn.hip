@@ -265,6 +265,7 @@ __global__ void __launch_bounds__(256) k_edge_gate(int N, const int32_t* __restr
 //   MODE 0: A = LayerNorm(A1); store                                   (GCN XW)
 //   MODE 1: A1 @ W1^T + A2 @ W2^T + bias -> LayerNorm -> GELU          (SAGE)
 //   MODE 2: A = LayerNorm(A1 * gvec[batch]); + bias -> GELU -> head -> softmax
+//   MODE 4: as MODE 2 without the LayerNorm (GATTrimapNet head)
 struct GemmArgs {
     const float *A1, *A2, *Wp1, *Wp2;
     const float *ln_w, *ln_b;        // prologue LayerNorm
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
             const float4 v = ap[q];
             a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
         }
-        if (MODE == 2) {
+        if (MODE == 2 || MODE == 4) {
             const float* gv = g.gvec + (size_t)g.batch[row] * D + hk * KH;
 #pragma unroll
             for (int s = 0; s < KH; ++s) a[s] *= gv[s];
@@ -984,7 +985,7 @@ static int launch_gemm(ggc_ctx* ctx, hipStream_t st, int N, const GemmArgs& a) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set.done(ctx->device);
     }
-    ProfScope prof(ctx, st, MODE == 0 ? "gcn_gemm" : MODE == 1 ? "sage_gemm" : MODE == 2 ? "head_gemm" : "plain_gemm");
+    ProfScope prof(ctx, st, MODE == 0 ? "gcn_gemm" : MODE == 1 ? "sage_gemm" : (MODE == 2 || MODE == 4) ? "head_gemm" : "plain_gemm");
     hipLaunchKernelGGL((k_gemm<D, MODE>), dim3(cdiv(N, 128)), dim3(256), lds, st, N, a);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
@@ -1428,7 +1429,7 @@ static BnW bn_of(const ResgcnWeights& m, const std::string& prefix) {
     return BnW{devp(m, prefix + "weight"), devp(m, prefix + "bias"), devp(m, prefix + "running_mean"), devp(m, prefix + "running_var")};
 }
 
-template <int D>
+template <int D, bool MUL_ONLY>
 static int launch_edge_gate(ggc_ctx* ctx, hipStream_t st, int N, const int32_t* row_ptr, const int32_t* eid, const int32_t* csr_dst,
                             const float* edge_attr, const float* w1T, const float* b1, const float* w2p, const float* b2,
                             const float* conv, const BnW& bn, const float* h, float* out);
@@ -1470,7 +1471,7 @@ static int forward_gcnnet_t(ggc_ctx* ctx, hipStream_t st, int N, int E, const fl
         if ((rc = launch_gemm<D, 3>(ctx, st, N, a))) return rc;
         if ((rc = launch_aggregate<D, 0>(ctx, st, N, xw, row_ptr, col, dis, devp(m, p + "conv.bias"), nullptr, nullptr, conv))) return rc;
         // edge MLP + scatter-mean + block epilogue in one kernel (k_gn_edge_gate below)
-        if ((rc = launch_edge_gate<D>(ctx, st, N, row_ptr, eid, csr_dst, edge_attr, devp(m, "#" + p + "edge_inject.proj.0.weightT"),
+        if ((rc = launch_edge_gate<D, false>(ctx, st, N, row_ptr, eid, csr_dst, edge_attr, devp(m, "#" + p + "edge_inject.proj.0.weightT"),
                                       devp(m, p + "edge_inject.proj.0.bias"), devp(m, "#" + p + "edge_inject.proj.2.weight.p"),
                                       devp(m, p + "edge_inject.proj.2.bias"), conv, bn_of(m, p + "bn."), h, out)))
             return rc;
@@ -1564,7 +1565,7 @@ namespace ggc {
 constexpr int EG_WAVES = 8, EG_NODES = 32;     // waves per block, destination nodes per wave
 constexpr int EG_STAGE = 66;                   // row stride of the sigmoid tile: two 32-column tiles + 2 words of padding
 
-template <int D>
+template <int D, bool MUL_ONLY>      // MUL_ONLY: out = conv * mean (GATTrimapNet: conv holds gelu(LayerNorm(GATv2)) already)
 __global__ void __launch_bounds__(64 * EG_WAVES) k_gn_edge_gate(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ eid,
                                                                 const int32_t* __restrict__ csr_dst,
                                                                 const float* __restrict__ edge_attr, const float* __restrict__ w1T,
@@ -1592,9 +1593,12 @@ __global__ void __launch_bounds__(64 * EG_WAVES) k_gn_edge_gate(int N, const int
         const int c = 32 * t + li;
         const int cnt = row_ptr[node + 1] - row_ptr[node];
         const float cf = (float)(cnt > 1 ? cnt : 1);
-        float v = bn_apply(conv[(size_t)node * D + c], bn, c);
-        v = v > 0.0f ? v : 0.0f;
-        v = v + h[(size_t)node * D + c];
+        float v = conv[(size_t)node * D + c];
+        if (!MUL_ONLY) {
+            v = bn_apply(v, bn, c);
+            v = v > 0.0f ? v : 0.0f;
+            v = v + h[(size_t)node * D + c];
+        }
         out[(size_t)node * D + c] = v * (sum / cf);
     };
     float sums[T];
@@ -1665,10 +1669,9 @@ __global__ void __launch_bounds__(64 * EG_WAVES) k_gn_edge_gate(int N, const int
                 const float bias = b2[32 * (t + tt) + li];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    // sigmoid on the transcendental unit: 1 / (1 + 2^(-x log2 e)), ~1e-7 relative
+                    // sigmoid as the shared IEEE sequence (include/ggc_fmath.h): the oracle produces the same bits
                     const float z = acc[t + tt][r] + bias;
-                    stage[((r & 3) + 8 * (r >> 2) + 4 * hk) * EG_STAGE + 32 * tt + li] =
-                        __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+                    stage[((r & 3) + 8 * (r >> 2) + 4 * hk) * EG_STAGE + 32 * tt + li] = ggc_sigmoid_nr(z);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1706,22 +1709,405 @@ __global__ void __launch_bounds__(64 * EG_WAVES) k_gn_edge_gate(int N, const int
     }
 }
 
-template <int D>
+template <int D, bool MUL_ONLY>
 static int launch_edge_gate(ggc_ctx* ctx, hipStream_t st, int N, const int32_t* row_ptr, const int32_t* eid, const int32_t* csr_dst,
                             const float* edge_attr, const float* w1T, const float* b1, const float* w2p, const float* b2,
                             const float* conv, const BnW& bn, const float* h, float* out) {
     const size_t lds = ((size_t)D * D + (size_t)EDGE_CH * D + D + (size_t)EG_WAVES * 32 * EG_STAGE) * sizeof(float);
     static DeviceOnce attr_set;
     if (attr_set.need(ctx->device)) {
-        GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gn_edge_gate<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        GGC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gn_edge_gate<D, MUL_ONLY>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
         attr_set.done(ctx->device);
     }
     ProfScope prof(ctx, st, "gcnnet_edge_gate");
-    hipLaunchKernelGGL((k_gn_edge_gate<D>), dim3(cdiv(N, EG_WAVES * EG_NODES)), dim3(64 * EG_WAVES), lds, st, N, row_ptr, eid, csr_dst,
+    hipLaunchKernelGGL((k_gn_edge_gate<D, MUL_ONLY>), dim3(cdiv(N, EG_WAVES * EG_NODES)), dim3(64 * EG_WAVES), lds, st, N, row_ptr, eid, csr_dst,
                        edge_attr, w1T, b1, w2p, b2, conv, bn, h, out);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
 }
 
 } // namespace ggc
+
+// ===================================================================================================
+// GATTrimapNet (reference model.py:323-414; SURVEY.md section 8(f), last rank): GATv2 attention with edge features.
+//   h0 = GELU(LN(Linear(BN(x))));  skip = skip_proj(h0)
+//   5 x { GATv2Conv(h) -> LN -> GELU -> EdgeInjectionLayer }   ;   h + skip -> GlobalContextModule -> head
+// GATv2Conv (PyG 2.x semantics, restated from its documentation — the library is absent, parity with it unpinned):
+// x_l = lin_l(x), x_r = lin_r(x) (both with bias), one self loop per node whose edge attribute is the MEAN of the node's
+// incoming edge attributes (fill_value="mean"); for an edge j -> i and head h
+//     m = leaky_relu(x_r[i] + x_l[j] + lin_edge(e_ij), 0.2);   a = att[h] . m[h];   alpha = softmax over the edges into i
+//     out_i[h] = sum_j alpha_ij x_l[j][h];   concat heads, + bias.
+// One wave per destination node (lane l holds channels l, l + 64): the per-head dot product is a butterfly over the head's
+// C = D / heads consecutive lanes; the softmax is two passes over the node's incoming edges in CSR (= edge) order, the
+// self loop last.  LayerNorm + GELU of the block are fused in (the wave holds the whole output row).  The per-block edge
+// gate is the fused MFMA kernel of GCNTrimapNet with a multiply-only epilogue; the D x D products run on k_gemm.
+// ===================================================================================================
+namespace ggc {
+
+template <int D>
+__global__ void __launch_bounds__(256) k_gat_input(int N, const float* __restrict__ x, BnW bn_in, const float* __restrict__ w_inT,
+                                                   const float* __restrict__ b_in, const float* __restrict__ ln_w,
+                                                   const float* __restrict__ ln_b, float* __restrict__ h) {
+    constexpr int NC = (D + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int node = wave; node < N; node += n_waves) {
+        float xn[IN_CH];
+#pragma unroll
+        for (int k = 0; k < IN_CH; ++k) xn[k] = bn_apply(x[(size_t)node * IN_CH + k], bn_in, k);
+        float a[NC];
+        float s1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            float acc = 0.0f;
+            if (c < D) {
+#pragma unroll
+                for (int k = 0; k < IN_CH; ++k) acc += xn[k] * w_inT[k * D + c];
+                acc += b_in[c];
+                s1 += acc;
+            }
+            a[j] = acc;
+        }
+        const float mean = wave_sum(s1) / (float)D;
+        float s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { const int c = lane + 64 * j; if (c < D) { const float dv = a[j] - mean; s2 += dv * dv; } }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)D + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) h[(size_t)node * D + c] = gelu_f((a[j] - mean) * rstd * ln_w[c] + ln_b[c]);
+        }
+    }
+}
+
+struct GatW { const float *bl, *br, *weT /*[5][D]*/, *att /*[D]*/, *bias, *ln_w, *ln_b; };
+
+template <int D, int HEADS>
+__global__ void __launch_bounds__(256) k_gat_attn(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                                  const int32_t* __restrict__ eid, const float* __restrict__ edge_attr,
+                                                  const float* __restrict__ xl, const float* __restrict__ xr, GatW w,
+                                                  float* __restrict__ out) {
+    constexpr int NC = (D + 63) / 64, C = D / HEADS;          // C in {4, 8, 16}: a head is C consecutive lanes
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    float bl[NC], att[NC], we[NC][EDGE_CH];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = lane + 64 * j;
+        bl[j] = c < D ? w.bl[c] : 0.0f; att[j] = c < D ? w.att[c] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < EDGE_CH; ++k) we[j][k] = c < D ? w.weT[k * D + c] : 0.0f;
+    }
+    for (int node = wave; node < N; node += n_waves) {
+        const int beg = row_ptr[node], end = row_ptr[node + 1], cnt = end - beg;
+        float xri[NC], xli[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            xri[j] = c < D ? xr[(size_t)node * D + c] + w.br[c] : 0.0f;
+            xli[j] = c < D ? xl[(size_t)node * D + c] + bl[j] : 0.0f;
+        }
+        // the self loop's edge attribute: mean of the incoming ones (sum in edge order / count; zeros without edges)
+        float am[EDGE_CH] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int p = beg; p < end; ++p) {
+            const float* a = edge_attr + (size_t)eid[p] * EDGE_CH;
+#pragma unroll
+            for (int k = 0; k < EDGE_CH; ++k) am[k] += a[k];
+        }
+        const float cf = (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+        for (int k = 0; k < EDGE_CH; ++k) am[k] = am[k] / cf;
+        // attention logit of one edge for this lane's head(s): every lane of a head ends with the head's value
+        auto logit = [&](const float* a, const float (&xlj)[NC], float (&lg)[NC]) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                float ev = 0.0f;
+#pragma unroll
+                for (int k = 0; k < EDGE_CH; ++k) ev += a[k] * we[j][k];
+                float m = (xri[j] + xlj[j]) + ev;
+                m = m > 0.0f ? m : 0.2f * m;
+                float v = m * att[j];
+#pragma unroll
+                for (int o = C / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                lg[j] = v;
+            }
+        };
+        float mx[NC], lgs[NC];
+        logit(am, xli, lgs);                                   // self loop
+#pragma unroll
+        for (int j = 0; j < NC; ++j) mx[j] = lgs[j];
+        for (int p = beg; p < end; ++p) {
+            const int src = col[p];
+            float xlj[NC], lg[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) { const int c = lane + 64 * j; xlj[j] = c < D ? xl[(size_t)src * D + c] + bl[j] : 0.0f; }
+            logit(edge_attr + (size_t)eid[p] * EDGE_CH, xlj, lg);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) mx[j] = fmaxf(mx[j], lg[j]);
+        }
+        float ssum[NC], acc[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { ssum[j] = 0.0f; acc[j] = 0.0f; }
+        for (int p = beg; p < end; ++p) {                      // the edges in order ...
+            const int src = col[p];
+            float xlj[NC], lg[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) { const int c = lane + 64 * j; xlj[j] = c < D ? xl[(size_t)src * D + c] + bl[j] : 0.0f; }
+            logit(edge_attr + (size_t)eid[p] * EDGE_CH, xlj, lg);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) { const float e = ggc_expf(lg[j] - mx[j]); ssum[j] += e; acc[j] += e * xlj[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { const float e = ggc_expf(lgs[j] - mx[j]); ssum[j] += e; acc[j] += e * xli[j]; }    // ... the self loop last
+        // + bias, LayerNorm, GELU
+        float o[NC];
+        float s1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            o[j] = c < D ? acc[j] / (ssum[j] + 1e-16f) + w.bias[c] : 0.0f;
+            if (c < D) s1 += o[j];
+        }
+        const float mean = wave_sum(s1) / (float)D;
+        float s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { const int c = lane + 64 * j; if (c < D) { const float dv = o[j] - mean; s2 += dv * dv; } }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)D + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) out[(size_t)node * D + c] = gelu_f((o[j] - mean) * rstd * w.ln_w[c] + w.ln_b[c]);
+        }
+    }
+}
+
+// h + skip and the readout score attn . (h + skip) + b
+template <int D>
+__global__ void __launch_bounds__(256) k_gat_score(int N, const float* __restrict__ h, const float* __restrict__ skip,
+                                                   const float* __restrict__ attn_w, const float* __restrict__ attn_b,
+                                                   float* __restrict__ hs, float* __restrict__ score) {
+    constexpr int NC = (D + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int node = wave; node < N; node += n_waves) {
+        float dot = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) {
+                const float v = h[(size_t)node * D + c] + skip[(size_t)node * D + c];
+                hs[(size_t)node * D + c] = v;
+                dot += v * attn_w[c];
+            }
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) score[node] = dot + attn_b[0];
+    }
+}
+
+static std::vector<Need> needed_gat(const ResgcnWeights& m) {
+    const int D = m.D, n = m.n_layers;
+    std::vector<Need> v;
+    for (const char* k : BN_KEYS) v.push_back({std::string("in_norm.norm.") + k, IN_CH});
+    v.push_back({"input_proj.0.weight", (int64_t)D * IN_CH}); v.push_back({"input_proj.0.bias", D});
+    v.push_back({"input_proj.1.weight", D}); v.push_back({"input_proj.1.bias", D});
+    for (int i = 0; i < n; ++i) {
+        const std::string s = std::to_string(i);
+        v.push_back({"convs." + s + ".att", D});
+        v.push_back({"convs." + s + ".lin_l.weight", (int64_t)D * D}); v.push_back({"convs." + s + ".lin_l.bias", D});
+        v.push_back({"convs." + s + ".lin_r.weight", (int64_t)D * D}); v.push_back({"convs." + s + ".lin_r.bias", D});
+        v.push_back({"convs." + s + ".lin_edge.weight", (int64_t)D * EDGE_CH}); v.push_back({"convs." + s + ".bias", D});
+        v.push_back({"lns." + s + ".weight", D}); v.push_back({"lns." + s + ".bias", D});
+        v.push_back({"edge_gates." + s + ".proj.0.weight", (int64_t)D * EDGE_CH}); v.push_back({"edge_gates." + s + ".proj.0.bias", D});
+        v.push_back({"edge_gates." + s + ".proj.2.weight", (int64_t)D * D}); v.push_back({"edge_gates." + s + ".proj.2.bias", D});
+    }
+    v.push_back({"skip_proj.weight", (int64_t)D * D});
+    v.push_back({"ctx.attn.weight", D}); v.push_back({"ctx.attn.bias", 1});
+    v.push_back({"ctx.compress.weight", (int64_t)(D / 2) * D}); v.push_back({"ctx.compress.bias", D / 2});
+    v.push_back({"ctx.expand.weight", (int64_t)D * (D / 2)}); v.push_back({"ctx.expand.bias", D});
+    v.push_back({"head.0.weight", (int64_t)D * D}); v.push_back({"head.0.bias", D});
+    v.push_back({"head.3.weight", (int64_t)N_CLS * D}); v.push_back({"head.3.bias", N_CLS});
+    return v;
+}
+
+static int check_ready_gat(ggc_ctx* ctx) {
+    ResgcnWeights& m = ctx->model3;
+    GGC_REQUIRE(ctx, m.D > 0, GGC_E_STATE, "ggc_gat_configure has not been called");
+    for (const Need& nd : needed_gat(m)) {
+        auto it = m.host.find(nd.key);
+        GGC_REQUIRE(ctx, it != m.host.end(), GGC_E_STATE, "missing weight '%s'", nd.key.c_str());
+        GGC_REQUIRE(ctx, (int64_t)it->second.size() == nd.numel, GGC_E_SHAPE, "weight '%s' has %zu elements, expected %lld",
+                    nd.key.c_str(), it->second.size(), (long long)nd.numel);
+    }
+    return GGC_OK;
+}
+
+static int prepare_weights_gat(ggc_ctx* ctx) {
+    ResgcnWeights& m = ctx->model3;
+    if (m.dev_ok) return GGC_OK;
+    int rc = check_ready_gat(ctx);
+    if (rc) return rc;
+    GGC_HIP(ctx, hipDeviceSynchronize());                  // (see prepare_weights)
+    const int D = m.D, n = m.n_layers;
+    for (auto& kv : m.host) { if ((rc = upload(ctx, m, kv.first, kv.second))) return rc; }
+    if ((rc = upload(ctx, m, "#input_proj.0.weightT", transpose(m.host["input_proj.0.weight"], D, IN_CH)))) return rc;
+    if ((rc = upload(ctx, m, "#skip_proj.weight.p", pack_mfma(m.host["skip_proj.weight"], D)))) return rc;
+    if ((rc = upload(ctx, m, "#ctx.compress.weightT", transpose(m.host["ctx.compress.weight"], D / 2, D)))) return rc;
+    if ((rc = upload(ctx, m, "#ctx.expand.weightT", transpose(m.host["ctx.expand.weight"], D, D / 2)))) return rc;
+    if ((rc = upload(ctx, m, "#head.0.weight.p", pack_mfma(m.host["head.0.weight"], D)))) return rc;
+    for (int i = 0; i < n; ++i) {
+        const std::string c = "convs." + std::to_string(i) + ".", g = "edge_gates." + std::to_string(i) + ".";
+        if ((rc = upload(ctx, m, "#" + c + "lin_l.weight.p", pack_mfma(m.host[c + "lin_l.weight"], D)))) return rc;
+        if ((rc = upload(ctx, m, "#" + c + "lin_r.weight.p", pack_mfma(m.host[c + "lin_r.weight"], D)))) return rc;
+        if ((rc = upload(ctx, m, "#" + c + "lin_edge.weightT", transpose(m.host[c + "lin_edge.weight"], D, EDGE_CH)))) return rc;
+        if ((rc = upload(ctx, m, "#" + g + "proj.0.weightT", transpose(m.host[g + "proj.0.weight"], D, EDGE_CH)))) return rc;
+        if ((rc = upload(ctx, m, "#" + g + "proj.2.weight.p", pack_mfma(m.host[g + "proj.2.weight"], D)))) return rc;
+    }
+    m.dev_ok = true;
+    return GGC_OK;
+}
+
+template <int D>
+static int forward_gat_t(ggc_ctx* ctx, hipStream_t st, int G, int N, int E, const float* x, const int32_t* edge_src,
+                         const int32_t* edge_dst, const float* edge_attr, const int32_t* node_ptr, float* logits, float* probs) {
+    ResgcnWeights& m = ctx->model3;
+    constexpr int HEADS = 8;
+    const int n = m.n_layers;
+    const size_t ND = (size_t)N * D;
+    int32_t* row_ptr = scratch_t<int32_t>(ctx, S_CSR_ROWPTR, (size_t)N + 1);
+    int32_t* col = scratch_t<int32_t>(ctx, S_CSR_COL, (size_t)std::max(E, 1));
+    int32_t* eid = scratch_t<int32_t>(ctx, S_CSR_EID, (size_t)std::max(E, 1));
+    int32_t* cursor = scratch_t<int32_t>(ctx, S_CSR_CURSOR, (size_t)N + 1);
+    float* dis = scratch_t<float>(ctx, S_DIS, (size_t)N);
+    int32_t* batch = scratch_t<int32_t>(ctx, S_BATCH, (size_t)N);
+    float* buf = scratch_t<float>(ctx, S_STATES, ND * 4);        // h (ping) | h (pong) | skip | gelu(LN(conv))
+    float* xl = scratch_t<float>(ctx, S_XW, ND);
+    float* xr = scratch_t<float>(ctx, S_AGG, ND);
+    float* hs = scratch_t<float>(ctx, S_HJK, ND);
+    float* score = scratch_t<float>(ctx, S_SCORE, (size_t)N);
+    float* gvec = scratch_t<float>(ctx, S_GVEC, (size_t)G * D);
+    if (!row_ptr || !col || !eid || !cursor || !dis || !batch || !buf || !xl || !xr || !hs || !score || !gvec) return GGC_E_OOM;
+    int rc = build_csr(ctx, st, N, E, edge_src, edge_dst, row_ptr, col, eid, cursor, dis);
+    if (rc) return rc;
+    int32_t* csr_dst = scratch_t<int32_t>(ctx, S_AGG_PACK, (size_t)std::max(E, 1));
+    if (!csr_dst) return GGC_E_OOM;
+    if (E > 0) {
+        hipLaunchKernelGGL(k_csr_dst, dim3(cdiv(E, 256)), dim3(256), 0, st, N, E, row_ptr, csr_dst);
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(k_fill_batch, dim3(min(cdiv(N, 256), 4096)), dim3(256), 0, st, G, N, node_ptr, batch);
+    GGC_LAUNCH_CHECK(ctx);
+    const int wave_blocks = min(cdiv(N, 4), 8 * ctx->n_cu);
+    float *h = buf, *h2 = buf + ND, *skip = buf + 2 * ND, *act = buf + 3 * ND;
+    hipLaunchKernelGGL((k_gat_input<D>), dim3(wave_blocks), dim3(256), 0, st, N, x, bn_of(m, "in_norm.norm."),
+                       devp(m, "#input_proj.0.weightT"), devp(m, "input_proj.0.bias"), devp(m, "input_proj.1.weight"),
+                       devp(m, "input_proj.1.bias"), h);
+    GGC_LAUNCH_CHECK(ctx);
+    {
+        GemmArgs a{};
+        a.A1 = h; a.Wp1 = devp(m, "#skip_proj.weight.p"); a.out = skip;
+        if ((rc = launch_gemm<D, 3>(ctx, st, N, a))) return rc;
+    }
+    for (int l = 0; l < n; ++l) {
+        const std::string c = "convs." + std::to_string(l) + ".", g = "edge_gates." + std::to_string(l) + ".", ln = "lns." + std::to_string(l) + ".";
+        GemmArgs a{};
+        a.A1 = h; a.Wp1 = devp(m, "#" + c + "lin_l.weight.p"); a.out = xl;
+        if ((rc = launch_gemm<D, 3>(ctx, st, N, a))) return rc;
+        a.Wp1 = devp(m, "#" + c + "lin_r.weight.p"); a.out = xr;
+        if ((rc = launch_gemm<D, 3>(ctx, st, N, a))) return rc;
+        GatW w{devp(m, c + "lin_l.bias"), devp(m, c + "lin_r.bias"), devp(m, "#" + c + "lin_edge.weightT"), devp(m, c + "att"),
+               devp(m, c + "bias"), devp(m, ln + "weight"), devp(m, ln + "bias")};
+        {
+            ProfScope prof(ctx, st, "gat_attention");
+            hipLaunchKernelGGL((k_gat_attn<D, HEADS>), dim3(wave_blocks), dim3(256), 0, st, N, row_ptr, col, eid, edge_attr, xl, xr, w, act);
+        }
+        GGC_LAUNCH_CHECK(ctx);
+        if ((rc = launch_edge_gate<D, true>(ctx, st, N, row_ptr, eid, csr_dst, edge_attr, devp(m, "#" + g + "proj.0.weightT"),
+                                            devp(m, g + "proj.0.bias"), devp(m, "#" + g + "proj.2.weight.p"), devp(m, g + "proj.2.bias"),
+                                            act, BnW{}, nullptr, h2)))
+            return rc;
+        std::swap(h, h2);
+    }
+    hipLaunchKernelGGL((k_gat_score<D>), dim3(wave_blocks), dim3(256), 0, st, N, h, skip, devp(m, "ctx.attn.weight"),
+                       devp(m, "ctx.attn.bias"), hs, score);
+    GGC_LAUNCH_CHECK(ctx);
+    {
+        CtxW w{devp(m, "#ctx.compress.weightT"), devp(m, "ctx.compress.bias"), devp(m, "#ctx.expand.weightT"), devp(m, "ctx.expand.bias")};
+        hipLaunchKernelGGL((k_graph_ctx<D>), dim3(G), dim3(256), 0, st, node_ptr, score, hs, w, gvec);
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    {
+        GemmArgs a{};
+        a.A1 = hs; a.Wp1 = devp(m, "#head.0.weight.p"); a.bias = devp(m, "head.0.bias");
+        a.batch = batch; a.gvec = gvec;
+        a.ep_w = devp(m, "head.3.weight"); a.ep_b = devp(m, "head.3.bias");
+        a.out = logits; a.out2 = probs;
+        if ((rc = launch_gemm<D, 4>(ctx, st, N, a))) return rc;
+    }
+    return GGC_OK;
+}
+
+} // namespace ggc
+
+extern "C" {
+
+int ggc_gat_configure(ggc_ctx* ctx, int hidden, int n_heads, int n_layers) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, hidden == 32 || hidden == 64 || hidden == 128, GGC_E_UNSUPPORTED,
+                "hidden_channels=%d unsupported: GATTrimapNet runs at 32, 64 or 128 (a head must span a power-of-two number of lanes)", hidden);
+    GGC_REQUIRE(ctx, n_heads == 8, GGC_E_UNSUPPORTED, "n_heads=%d unsupported: the attention kernel is built for the reference's 8 heads", n_heads);
+    GGC_REQUIRE(ctx, n_layers >= 1 && n_layers <= 30, GGC_E_INVALID_ARG, "n_layers=%d out of range [1,30]", n_layers);
+    ResgcnWeights& m = ctx->model3;
+    if (m.D != hidden || m.n_layers != n_layers) m.host.clear();
+    m.D = hidden; m.n_layers = n_layers; m.Q = n_heads; m.dev_ok = false;
+    return GGC_OK;
+}
+
+int ggc_gat_load_weight(ggc_ctx* ctx, const char* name, const float* data, int64_t numel) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, name && (data || numel == 0) && numel >= 0, GGC_E_INVALID_ARG, "bad weight arguments");
+    GGC_REQUIRE(ctx, ctx->model3.D > 0, GGC_E_STATE, "ggc_gat_configure has not been called");
+    const std::string key(name), tail = "num_batches_tracked";
+    if (key.size() >= tail.size() && key.compare(key.size() - tail.size(), tail.size(), tail) == 0) return GGC_OK;
+    bool known = false;
+    for (const Need& nd : needed_gat(ctx->model3))
+        if (nd.key == key) {
+            GGC_REQUIRE(ctx, nd.numel == numel, GGC_E_SHAPE, "weight '%s' has %lld elements, expected %lld", name,
+                        (long long)numel, (long long)nd.numel);
+            known = true;
+            break;
+        }
+    GGC_REQUIRE(ctx, known, GGC_E_INVALID_ARG, "unexpected state_dict key '%s' for GATTrimapNet(D=%d, n=%d)", name,
+                ctx->model3.D, ctx->model3.n_layers);
+    ctx->model3.host[key].assign(data, data + numel);
+    ctx->model3.dev_ok = false;
+    return GGC_OK;
+}
+
+int ggc_gat_ready(ggc_ctx* ctx) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    return check_ready_gat(ctx);
+}
+
+int ggc_gat_forward(ggc_ctx* ctx, ggc_stream stream, int G, int N, int E, const float* x, const int32_t* edge_src,
+                    const int32_t* edge_dst, const float* edge_attr, const int32_t* node_ptr, float* logits, float* probs) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, G >= 1 && N >= 1 && E >= 0, GGC_E_SHAPE, "bad sizes G=%d N=%d E=%d", G, N, E);
+    GGC_REQUIRE(ctx, x && node_ptr && (E == 0 || (edge_src && edge_dst && edge_attr)), GGC_E_INVALID_ARG, "null input pointer");
+    GGC_REQUIRE(ctx, logits || probs, GGC_E_INVALID_ARG, "both outputs are NULL");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = prepare_weights_gat(ctx);
+    if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (ctx->model3.D) {
+        case 32:  return forward_gat_t<32>(ctx, st, G, N, E, x, edge_src, edge_dst, edge_attr, node_ptr, logits, probs);
+        case 64:  return forward_gat_t<64>(ctx, st, G, N, E, x, edge_src, edge_dst, edge_attr, node_ptr, logits, probs);
+        case 128: return forward_gat_t<128>(ctx, st, G, N, E, x, edge_src, edge_dst, edge_attr, node_ptr, logits, probs);
+    }
+    return set_err(ctx, GGC_E_STATE, "model not configured");
+}
+
+} // extern "C"

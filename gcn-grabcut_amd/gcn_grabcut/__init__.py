@@ -15,7 +15,7 @@ from .graph_builder import (
 )
 from .metrics import evaluate, evaluate_batch, evaluate_trimap, boundary_f1, SegmentationMetrics, TrimapMetrics
 from .model import (
-    ResGCNNet, GCNTrimapNet, build_model, _probs_to_trimap, probs_to_node_trimap, project_to_pixels,
+    ResGCNNet, GCNTrimapNet, GATTrimapNet, build_model, _probs_to_trimap, probs_to_node_trimap, project_to_pixels,
     TRIMAP_BG, TRIMAP_FG, TRIMAP_PROB_BG, TRIMAP_PROB_FG, CLASS_BG, CLASS_UNK, CLASS_FG,
 )
 from .pipeline import GCNGrabCutPipeline, SegmentationResult, clean_mask, guided_filter, refine_trimap
@@ -29,6 +29,6 @@ __all__ = [
     "N_NODE_FEATS", "N_EDGE_FEATS", "N_PRIOR_FEATS",
     "evaluate", "evaluate_batch", "evaluate_trimap", "boundary_f1", "SegmentationMetrics", "TrimapMetrics",
     "GCNGrabCutPipeline", "SegmentationResult", "clean_mask", "guided_filter", "refine_trimap",
-    "ResGCNNet", "GCNTrimapNet", "build_model", "probs_to_node_trimap", "project_to_pixels",
+    "ResGCNNet", "GCNTrimapNet", "GATTrimapNet", "build_model", "probs_to_node_trimap", "project_to_pixels",
     "Data", "Batch", "synthetic_image", "synthetic_batch",
 ]

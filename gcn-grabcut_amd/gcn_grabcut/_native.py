@@ -48,6 +48,10 @@ SIGNATURES = {
     "ggc_gcnnet_load_weight": [_vp, C.c_char_p, _vp, _i64],
     "ggc_gcnnet_ready": [_vp],
     "ggc_gcnnet_forward": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ggc_gat_configure": [_vp, _i, _i, _i],
+    "ggc_gat_load_weight": [_vp, C.c_char_p, _vp, _i64],
+    "ggc_gat_ready": [_vp],
+    "ggc_gat_forward": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ggc_gcn_aggregate": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ggc_build_csr": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ggc_refine_trimap": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _i, _vp],

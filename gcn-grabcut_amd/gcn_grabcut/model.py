@@ -392,6 +392,134 @@ if _TORCH:
         def predict_trimap(self, data, segments: np.ndarray, threshold_fg: float = 0.55, threshold_bg: float = 0.55) -> np.ndarray:
             return _probs_to_trimap(self.predict_probs(data), segments, threshold_fg, threshold_bg)
 
+
+    def _node_ptr_of(data, n: int, dev) -> "torch.Tensor":
+        """int32 prefix sums of the graphs' node counts from data.node_ptr32 / data.batch (contiguous graphs, PyG Batch)."""
+        node_ptr = getattr(data, "node_ptr32", None)
+        if node_ptr is not None:
+            return node_ptr
+        batch = getattr(data, "batch", None)
+        if batch is None:
+            return torch.tensor([0, n], dtype=torch.int32, device=dev)
+        n_graphs = getattr(data, "num_graphs", None)
+        if n_graphs is None:
+            n_graphs = int(batch.max().item()) + 1                   # reference model.py:86
+        counts = torch.bincount(batch, minlength=n_graphs)
+        node_ptr = torch.zeros(n_graphs + 1, dtype=torch.int32, device=dev)
+        node_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        return node_ptr
+
+    class _GATv2Params(nn.Module):
+        """Parameter holder with the state_dict keys of torch_geometric.nn.GATv2Conv(D, D // H, heads=H, concat=True,
+        edge_dim=5, share_weights=False): att [1,H,C], lin_l / lin_r (with bias), lin_edge (no bias), bias [D]."""
+        def __init__(self, dim: int, heads: int, edge_dim: int):
+            super().__init__()
+            c = dim // heads
+            self.att = nn.Parameter(torch.empty(1, heads, c))
+            self.lin_l = nn.Linear(dim, heads * c)
+            self.lin_r = nn.Linear(dim, heads * c)
+            self.lin_edge = nn.Linear(edge_dim, heads * c, bias=False)
+            self.bias = nn.Parameter(torch.zeros(heads * c))
+            nn.init.xavier_uniform_(self.att)                       # PyG's glorot
+
+    class GATTrimapNet(nn.Module):
+        """
+        GATv2 attention variant with edge features (reference model.py:323-414; SURVEY.md section 8(f), last rank).  Same
+        `state_dict` keys as the reference module.  Inference only: the forward pass runs in libggc_hip.so
+        (`ggc_gat_forward`) on an MI355X — there is no CPU fallback.  Widths 32, 64 or 128 with the reference's 8 heads.
+        """
+
+        def __init__(self, in_channels: int = N_NODE_FEATS, edge_channels: int = N_EDGE_FEATS, hidden_channels: int = 128,
+                     n_heads: int = 8, n_layers: int = 5, n_classes: int = 3, dropout: float = 0.2):
+            super().__init__()
+            if in_channels != N_NODE_FEATS or edge_channels != N_EDGE_FEATS or n_classes != 3:
+                raise ValueError("the MI355X kernels are built for 19 node features, 5 edge features and 3 classes")
+            if hidden_channels not in (32, 64, 128) or n_heads != 8:
+                raise ValueError("GATTrimapNet on MI355X: hidden_channels in {32, 64, 128} with n_heads = 8 "
+                                 "(a head must span a power-of-two number of lanes)")
+            self.n_classes, self.n_heads, self.hidden_channels, self.n_layers = n_classes, n_heads, hidden_channels, n_layers
+            self.in_norm = _InputNorm(in_channels)
+            self.input_proj = nn.Sequential(nn.Linear(in_channels, hidden_channels), nn.LayerNorm(hidden_channels), nn.GELU())
+            self.convs = nn.ModuleList([_GATv2Params(hidden_channels, n_heads, edge_channels) for _ in range(n_layers)])
+            self.lns = nn.ModuleList([nn.LayerNorm(hidden_channels) for _ in range(n_layers)])
+            self.edge_gates = nn.ModuleList([_EdgeInjection(edge_channels, hidden_channels) for _ in range(n_layers)])
+            self.dropout = dropout
+            self.skip_proj = nn.Linear(hidden_channels, hidden_channels, bias=False)
+            self.ctx = _GlobalContext(hidden_channels)
+            self.head = nn.Sequential(nn.Linear(hidden_channels, hidden_channels), nn.GELU(), nn.Dropout(dropout),
+                                      nn.Linear(hidden_channels, n_classes))
+            self._uid = next(_model_uid)
+
+        def _device_index(self) -> int:
+            dev = self.head[0].weight.device
+            if dev.type != "cuda":
+                raise RuntimeError("GATTrimapNet runs on an MI355X through libggc_hip.so only; "
+                                   f"the model is on '{dev}'. Move it with .to('cuda') — there is no CPU fallback.")
+            return dev.index if dev.index is not None else torch.cuda.current_device()
+
+        def _sync_weights(self, ctx: "_native.Context") -> None:
+            sd = self.state_dict()
+            fp = (self._uid, tuple((k, v.data_ptr(), v._version) for k, v in sd.items()))
+            if ctx.resident.get("gat") == fp:
+                return
+            ctx.call("ggc_gat_configure", self.hidden_channels, self.n_heads, self.n_layers)
+            for k, v in sd.items():
+                if not v.dtype.is_floating_point:
+                    continue   # num_batches_tracked
+                a = v.detach().to(device="cpu", dtype=torch.float32).contiguous().numpy()
+                ctx.call("ggc_gat_load_weight", k.encode(), a.ctypes.data, a.size)
+            ctx.call("ggc_gat_ready")
+            ctx.resident["gat"] = fp
+
+        def _run(self, data, want_logits: bool, want_probs: bool, ctx=None):
+            if self.training:
+                raise RuntimeError("GATTrimapNet on MI355X is inference-only: call .eval() first")
+            dev_index = self._device_index()
+            if ctx is None:
+                ctx = _native.get_context(dev_index)
+            self._sync_weights(ctx)
+            dev = torch.device("cuda", dev_index)
+            x = data.x
+            if x.device != dev:
+                raise RuntimeError(f"data.x is on {x.device}, model on {dev}")
+            x = x.to(torch.float32).contiguous()
+            n = x.size(0)
+            if x.dim() != 2 or x.size(1) != N_NODE_FEATS:
+                raise ValueError(f"data.x must be (N, {N_NODE_FEATS}), got {tuple(x.shape)}")
+            ei = data.edge_index
+            e = ei.size(1)
+            edge_attr = getattr(data, "edge_attr", None)
+            if edge_attr is None:                      # reference model.py:383-384
+                edge_attr = torch.zeros(e, N_EDGE_FEATS, device=dev)
+            edge_attr = edge_attr.to(torch.float32).contiguous()
+            src, dst = ei[0].to(torch.int32).contiguous(), ei[1].to(torch.int32).contiguous()
+            node_ptr = _node_ptr_of(data, n, dev)
+            logits = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_logits else None
+            probs = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_probs else None
+            ctx.call("ggc_gat_forward", _native.current_stream(dev_index), node_ptr.numel() - 1, n, e, x.data_ptr(), src.data_ptr(),
+                     dst.data_ptr(), edge_attr.data_ptr(), node_ptr.data_ptr(), _native.ptr(logits), _native.ptr(probs))
+            return logits, probs
+
+        def forward(self, data) -> "torch.Tensor":
+            """logits (N, 3) on the model's device — reference model.py:380-404."""
+            with torch.no_grad():
+                return self._run(data, True, False)[0]
+
+        @torch.no_grad()
+        def predict_probs(self, data) -> np.ndarray:
+            self.eval()
+            return self._run(data, False, True)[1].float().cpu().numpy()
+
+        @torch.no_grad()
+        def predict_probs_device(self, data, ctx=None) -> "torch.Tensor":
+            if self.training:
+                self.eval()
+            return self._run(data, False, True, ctx)[1]
+
+        @torch.no_grad()
+        def predict_trimap(self, data, segments: np.ndarray, threshold_fg: float = 0.55, threshold_bg: float = 0.55) -> np.ndarray:
+            return _probs_to_trimap(self.predict_probs(data), segments, threshold_fg, threshold_bg)
+
     def build_model(
         variant: str = "resgcn",
         in_channels: int = N_NODE_FEATS,
@@ -401,7 +529,7 @@ if _TORCH:
         n_classes: int = 3,
         dropout: float = 0.2,
     ) -> "nn.Module":
-        """Factory by name (reference model.py:593-620): "resgcn" (hot path) and "gcn" run on the MI355X."""
+        """Factory by name (reference model.py:593-620): "resgcn" (hot path), "gcn" and "gat" all run on the MI355X."""
         if variant == "resgcn":
             return ResGCNNet(in_channels=in_channels, edge_channels=edge_channels,
                              hidden_channels=hidden_channels, n_layers=n_layers,
@@ -410,8 +538,9 @@ if _TORCH:
             return GCNTrimapNet(in_channels=in_channels, edge_channels=edge_channels, hidden_channels=hidden_channels,
                                 n_layers=n_layers, n_classes=n_classes, dropout=dropout)
         if variant == "gat":
-            raise NotImplementedError(
-                "variant 'gat' (GATv2 attention) is not built for the MI355X (SURVEY section 8(f), last rank); use 'resgcn' or 'gcn'")
+            # the reference's factory passes n_layers through unchanged (its class default is 5, the factory's 6)
+            return GATTrimapNet(in_channels=in_channels, edge_channels=edge_channels, hidden_channels=hidden_channels,
+                                n_layers=n_layers, n_classes=n_classes, dropout=dropout)
         raise ValueError(f"Unknown variant '{variant}'. Choose: resgcn | gcn | gat")
 
 

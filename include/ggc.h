@@ -187,6 +187,20 @@ int ggc_gcnnet_forward(ggc_ctx* ctx, ggc_stream stream, int N, int E,
                        const float* x, const int32_t* edge_src, const int32_t* edge_dst,
                        const float* edge_attr, float* logits, float* probs);
 
+/* GATTrimapNet, the reference's attention variant (`--model gat`, model.py:323-414; SURVEY 8(f) last rank), eval mode: GATv2
+ * attention with edge features (8 heads), LayerNorm + GELU, per-block edge gates, skip, per-graph attention readout, head.
+ * Same protocol: configure, load every float tensor of the state_dict by its key ("convs.0.att", "convs.0.lin_l.weight",
+ * "convs.0.lin_edge.weight", "lns.0.weight", "edge_gates.0.proj.2.bias", "skip_proj.weight", "ctx.attn.weight",
+ * "head.3.weight", ...), then forward.  hidden_channels in {32, 64, 128}, n_heads == 8.  Arguments as ggc_resgcn_forward
+ * (node_ptr delimits the graphs of the batch for the readout). */
+int ggc_gat_configure(ggc_ctx* ctx, int hidden_channels, int n_heads, int n_layers);
+int ggc_gat_load_weight(ggc_ctx* ctx, const char* name, const float* data /*[host]*/, int64_t numel);
+int ggc_gat_ready(ggc_ctx* ctx);
+int ggc_gat_forward(ggc_ctx* ctx, ggc_stream stream, int G, int N, int E,
+                    const float* x, const int32_t* edge_src, const int32_t* edge_dst,
+                    const float* edge_attr, const int32_t* node_ptr,
+                    float* logits, float* probs);
+
 /* M3 alone — the GCNConv scatter-gather the north star grades (PyG GCNConv
  * inside model.py:523-528).  CSR over destinations, self loops implicit.
  *   out_i = sum_{e: dst(e)=i} dis[src]*dis[i]*xw[src] + dis[i]*dis[i]*xw[i] + bias

@@ -26,7 +26,7 @@
 GGC_FM_FN float ggc_fm_from_bits(uint32_t u) { float f; memcpy(&f, &u, sizeof f); return f; }
 GGC_FM_FN uint32_t ggc_fm_to_bits(float f) { uint32_t u; memcpy(&u, &f, sizeof u); return u; }
 
-/* 1 / d for d in [1, 16]: integer seed (12 % off) and three Newton steps r <- r (2 - d r), each one fused multiply-add and
+/* 1 / d for a positive normal d (used on [1, 7e37]): integer seed (12 % off) and three Newton steps r <- r (2 - d r), each one fused multiply-add and
  * one multiply; relative error 1.2e-7.  Not the correctly rounded quotient, but the same bits everywhere, and a third of the
  * instructions of an IEEE divide on the GPU (it vectorises on the packed-f32 pipe). */
 GGC_FM_FN float ggc_rcp_nr(float d) {
@@ -58,6 +58,9 @@ GGC_FM_FN float ggc_expf(float x) {
 }
 
 GGC_FM_FN float ggc_sigmoidf(float x) { return 1.0f / (1.0f + ggc_expf(-x)); }
+/* the same with the Newton reciprocal (relative error 2e-7): the per-edge gates of GCNTrimapNet / GATTrimapNet evaluate 2e8 of
+ * these per block, inside an MFMA kernel */
+GGC_FM_FN float ggc_sigmoid_nr(float x) { return ggc_rcp_nr(1.0f + ggc_expf(-x)); }
 
 /* GELU(x) = x Phi(x), Phi through erfc: with t = |x| / sqrt 2 and u = 1 / (1 + p t),
  *     erfc(t) ~= (a1 u + ... + a6 u^6) exp(-t^2),  |error| < 8e-9 on [0, 6.5]

@@ -65,14 +65,12 @@ def main() -> None:
     import torch
     from src.gcn_grabcut import GCNGrabCutPipeline
     from src.gcn_grabcut.graph_builder import SuperpixelGraphConfig
-    from src.gcn_grabcut.model import GCNTrimapNet, ResGCNNet
+    from src.gcn_grabcut.model import GATTrimapNet, GCNTrimapNet, ResGCNNet
     from src.gcn_grabcut.pipeline import _colour_trimap, _write_png
 
     if not torch.cuda.is_available():
         raise SystemExit("[inference] no MI355X visible: this build has no CPU path")
-    if args.model == "gat":
-        raise SystemExit("[inference] --model gat (GATv2 attention) is not built for the MI355X; use resgcn or gcn")
-    model_cls = {"resgcn": ResGCNNet, "gcn": GCNTrimapNet}[args.model]
+    model_cls = {"resgcn": ResGCNNet, "gcn": GCNTrimapNet, "gat": GATTrimapNet}[args.model]
 
     ckpt_path = Path(args.checkpoint)
     if not ckpt_path.exists():
@@ -85,7 +83,8 @@ def main() -> None:
     # width and depth are recovered from the checkpoint (reference inference.py:81-86)
     hidden = state["input_proj.0.weight"].shape[0] if "input_proj.0.weight" in state else args.hidden
     layers = (sum(1 for k in state if k.startswith("gcn_layers.") and k.endswith(".bias"))
-              or sum(1 for k in state if k.startswith("blocks.") and k.endswith(".conv.bias")) or args.layers)
+              or sum(1 for k in state if k.startswith("blocks.") and k.endswith(".conv.bias"))
+              or sum(1 for k in state if k.startswith("convs.") and k.endswith(".att")) or args.layers)
     model = model_cls(hidden_channels=hidden, n_layers=layers)
     model.load_state_dict(state)
     model.eval()

@@ -80,7 +80,7 @@ int ggo_gcnnet_forward(const float* const* P, int D, int n_layers, int N, int E,
             for (int k = 0; k < D; ++k) e1[k] = e1[k] > 0.0f ? e1[k] : 0.0f;
             linear_row(e1, B[8], B[9], D, D, e2);
             float* gr = gates + (size_t)dst[e] * D;
-            for (int k = 0; k < D; ++k) gr[k] += sigmoid_f(e2[k]);
+            for (int k = 0; k < D; ++k) gr[k] += ggc_sigmoid_nr(e2[k]);        /* the kernel's form (include/ggc_fmath.h) */
             cnt[dst[e]] += 1.0f;
         }
         for (int i = 0; i < N; ++i) {

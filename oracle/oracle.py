@@ -115,6 +115,39 @@ def gcnnet_forward(state: dict, hidden: int, n_layers: int, x, edge_index, edge_
     return logits, probs
 
 
+def gat_param_order(n_layers: int) -> list[str]:
+    """GATTrimapNet state_dict keys in the order oracle/gat.c expects."""
+    keys = [f"in_norm.norm.{k}" for k in ("weight", "bias", "running_mean", "running_var")]
+    keys += ["input_proj.0.weight", "input_proj.0.bias", "input_proj.1.weight", "input_proj.1.bias"]
+    for i in range(n_layers):
+        keys += [f"convs.{i}.att", f"convs.{i}.lin_l.weight", f"convs.{i}.lin_l.bias", f"convs.{i}.lin_r.weight", f"convs.{i}.lin_r.bias",
+                 f"convs.{i}.lin_edge.weight", f"convs.{i}.bias", f"lns.{i}.weight", f"lns.{i}.bias",
+                 f"edge_gates.{i}.proj.0.weight", f"edge_gates.{i}.proj.0.bias", f"edge_gates.{i}.proj.2.weight", f"edge_gates.{i}.proj.2.bias"]
+    keys += ["skip_proj.weight", "ctx.attn.weight", "ctx.attn.bias", "ctx.compress.weight", "ctx.compress.bias",
+             "ctx.expand.weight", "ctx.expand.bias", "head.0.weight", "head.0.bias", "head.3.weight", "head.3.bias"]
+    return keys
+
+
+def gat_forward(state: dict, hidden: int, n_layers: int, x, edge_index, edge_attr, batch=None):
+    """GATTrimapNet (eval, 8 heads). state: {key: np.ndarray}. Returns (logits, probs) float32 (N,3)."""
+    L = lib()
+    keys = gat_param_order(n_layers)
+    assert L.ggo_gat_n_params(n_layers) == len(keys)
+    arrs = [f32(np.asarray(state[k])) for k in keys]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    x = f32(x)
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    ea = f32(edge_attr)
+    n, e = x.shape[0], ei.shape[1]
+    b = None if batch is None else np.ascontiguousarray(batch, dtype=np.int64)
+    ng = 1 if b is None else int(b.max()) + 1
+    logits = np.empty((n, 3), np.float32)
+    probs = np.empty((n, 3), np.float32)
+    rc = L.ggo_gat_forward(ptrs, _i(hidden), _i(n_layers), _i(n), _i(e), _p(x), _p(ei), _p(ea), _p(b), _i(ng), _p(logits), _p(probs))
+    assert rc == 0, rc
+    return logits, probs
+
+
 def gcn_aggregate(xw, edge_index, bias=None, gate=None, h=None):
     L = lib()
     xw = f32(xw)

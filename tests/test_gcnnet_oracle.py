@@ -37,8 +37,8 @@ def test_state_dict_layout_and_parameter_count():
     assert sd["blocks.0.conv.lin.weight"].shape == (128, 128) and sd["blocks.5.edge_inject.proj.0.weight"].shape == (128, 5)
     assert sd["head.0.weight"].shape == (128, 128 * 7) and sd["head.6.weight"].shape == (3, 64)
     assert isinstance(build_model("gcn", hidden_channels=32, n_layers=2), GCNTrimapNet)
-    with pytest.raises(NotImplementedError):
-        build_model("gat")
+    with pytest.raises(ValueError):
+        build_model("transformer")
     # learnable parameters: in_norm 38 + input 19D+D+2D + blocks n(D^2 + D + 2D + 5D + D + D^2 + D) + head
     d, n = 128, 6
     want = 38 + (19 * d + d + 2 * d) + n * (2 * d * d + 10 * d) + (d * d * (n + 1) + d + 2 * d) + (d * d // 2 + d // 2) + (3 * d // 2 + 3)

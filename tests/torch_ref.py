@@ -106,3 +106,54 @@ def gcnnet_forward(sd, n_layers, x, edge_index, edge_attr):
     z = F.relu(F.linear(z, sd["head.4.weight"], sd["head.4.bias"]))
     logits = F.linear(z, sd["head.6.weight"], sd["head.6.bias"])
     return logits, torch.softmax(logits, dim=-1)
+
+
+def gatv2_conv(x, edge_index, edge_attr, sd, p, heads):
+    """torch_geometric.nn.GATv2Conv(D, D // heads, heads, concat=True, edge_dim=5, share_weights=False) in eval mode, from its
+    documented semantics (add_self_loops=True with fill_value="mean", negative_slope 0.2, softmax over the edges into a node)."""
+    n, d = x.size(0), sd[p + "lin_l.weight"].size(0)
+    c = d // heads
+    x_l = F.linear(x, sd[p + "lin_l.weight"], sd[p + "lin_l.bias"]).view(n, heads, c)
+    x_r = F.linear(x, sd[p + "lin_r.weight"], sd[p + "lin_r.bias"]).view(n, heads, c)
+    loops = torch.arange(n, dtype=edge_index.dtype)
+    loop_attr = scatter_mean(edge_attr, edge_index[1], n)                  # self-loop attribute: mean of the incoming ones
+    src = torch.cat([edge_index[0], loops]); dst = torch.cat([edge_index[1], loops])
+    ea = torch.cat([edge_attr, loop_attr], 0)
+    m = x_r[dst] + x_l[src] + F.linear(ea, sd[p + "lin_edge.weight"]).view(-1, heads, c)
+    m = F.leaky_relu(m, 0.2)
+    alpha = (m * sd[p + "att"]).sum(-1)                                    # (E + N, heads)
+    peak = torch.full((n, heads), float("-inf")).index_reduce(0, dst, alpha, "amax", include_self=True)
+    ex = torch.exp(alpha - peak[dst])
+    tot = torch.zeros(n, heads).index_add_(0, dst, ex)
+    alpha = ex / (tot[dst] + 1e-16)
+    out = torch.zeros(n, heads, c).index_add_(0, dst, alpha.unsqueeze(-1) * x_l[src])
+    return out.reshape(n, d) + sd[p + "bias"]
+
+
+@torch.no_grad()
+def gat_forward(sd, n_layers, x, edge_index, edge_attr, batch=None, heads=8):
+    """GATTrimapNet.forward in eval mode (reference model.py:380-404).  sd: state_dict of float32 CPU tensors, reference keys."""
+    n = x.size(0)
+    d = sd["input_proj.0.weight"].size(0)
+    xn = F.batch_norm(x, sd["in_norm.norm.running_mean"], sd["in_norm.norm.running_var"],
+                      sd["in_norm.norm.weight"], sd["in_norm.norm.bias"], False, 0.0, 1e-5)
+    h = F.gelu(F.layer_norm(F.linear(xn, sd["input_proj.0.weight"], sd["input_proj.0.bias"]), (d,),
+                            sd["input_proj.1.weight"], sd["input_proj.1.bias"]))
+    skip = F.linear(h, sd["skip_proj.weight"])
+    for i in range(n_layers):
+        hn = F.gelu(F.layer_norm(gatv2_conv(h, edge_index, edge_attr, sd, f"convs.{i}.", heads), (d,), sd[f"lns.{i}.weight"], sd[f"lns.{i}.bias"]))
+        g = torch.sigmoid(F.linear(F.relu(F.linear(edge_attr, sd[f"edge_gates.{i}.proj.0.weight"], sd[f"edge_gates.{i}.proj.0.bias"])),
+                                   sd[f"edge_gates.{i}.proj.2.weight"], sd[f"edge_gates.{i}.proj.2.bias"]))
+        h = hn * scatter_mean(g, edge_index[1], n)
+    h = h + skip
+    a = graph_softmax(F.linear(h, sd["ctx.attn.weight"], sd["ctx.attn.bias"]), batch)
+    if batch is None:
+        g = (a * h).sum(0, keepdim=True)
+    else:
+        ng = int(batch.max()) + 1
+        g = torch.zeros(ng, d).index_add_(0, batch, a * h)[batch]
+    g = torch.sigmoid(F.linear(F.relu(F.linear(g, sd["ctx.compress.weight"], sd["ctx.compress.bias"])),
+                               sd["ctx.expand.weight"], sd["ctx.expand.bias"]))
+    z = F.gelu(F.linear(h * g, sd["head.0.weight"], sd["head.0.bias"]))
+    logits = F.linear(z, sd["head.3.weight"], sd["head.3.bias"])
+    return logits, torch.softmax(logits, dim=-1)
