@@ -25,6 +25,7 @@
 //    counters let the launch that consumes list L also clear the counter of list L+2.
 //  * images without active pixels leave the open-image list; converged tiles cost nothing.
 #include "ggc_gc.h"
+#include "ggc_mf_sweep.h"
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -32,7 +33,10 @@
 
 namespace ggc {
 
-constexpr int RT = MF_RT;              // relabel tile side
+#ifndef GGC_MF_HOST_RT
+#define GGC_MF_HOST_RT MF_RT
+#endif
+constexpr int RT = GGC_MF_HOST_RT;    // relabel tile side of this driver (experiments: -DGGC_MF_HOST_RT=64)
 constexpr int RT_ROWS = 256 / RT;      // tile rows covered by one pass of the 256 threads
 constexpr int RT_NJ = RT * RT / 256;   // pixels per thread
 constexpr int PT_W = MF_PT_W, PT_H = MF_PT_H;   // push tile (32x16 measured 6 % slower end to end)
@@ -181,6 +185,92 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
             if (ty >= 0 && ty < tl.rt_y && tx >= 0 && tx < tl.rt_x)
                 push_tile(b * tiles_per_image + ty * tl.rt_x + tx, flag_out, list_out, n_out);
         }
+    }
+}
+
+// The same relabel with a WAVE per tile (4 tiles per block, no block barrier): the labels are relaxed by alternating
+// vertical and horizontal in-register sweeps (ggc_mf_sweep.h), which carry a front across the tile in a handful of
+// sweeps where the neighbour-at-a-time iteration above needs one per pixel of the way.  32x32 tiles only.
+struct RelaxWaveLds { int d[MF_RT + 2][MF_RT + 2]; uint32_t m[MF_RT][MF_RT / 4]; };
+__global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int phase, const uint8_t* __restrict__ rmask,
+                                                       int32_t* __restrict__ dist, int32_t* __restrict__ counters,
+                                                       const int32_t* __restrict__ list_in, int32_t* __restrict__ list_out,
+                                                       int32_t* __restrict__ flag_in, int32_t* __restrict__ flag_out) {
+    constexpr int T = MF_RT, N_HALO = (T + 2) * (T + 2), HALO_IT = (N_HALO + 63) / 64;
+    __shared__ RelaxWaveLds lds[4];
+    const int wv = threadIdx.x >> 6;
+    RelaxWaveLds& S = lds[wv];
+    const int n_in = counters[phase % 3];
+    int32_t* n_out = counters + (phase + 1) % 3;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[(phase + 2) % 3] = 0;       // the list after next starts empty
+    const int tiles_per_image = tl.rt_x * tl.rt_y;
+    const int G = gridDim.x * 4;
+    int* sd = &S.d[0][0];
+    uint8_t* sm = reinterpret_cast<uint8_t*>(&S.m[0][0]);
+    for (int t = blockIdx.x * 4 + wv; t < n_in; t += G) {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));                                     // keeps the lane arithmetic inside the loop (no hoist + spill)
+        const int tile = __builtin_amdgcn_readfirstlane(list_in[t]);
+        const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
+        const int tyi = tr / tl.rt_x, txi = tr % tl.rt_x;
+        const int tx0 = txi * T, ty0 = tyi * T;
+        const size_t base = (size_t)b * d.P;
+        const int lx = lane & 31, h = lane >> 5;
+        int hv[HALO_IT];
+#pragma unroll
+        for (int k = 0; k < HALO_IT; ++k) {                                // unconditional loads from clamped addresses
+            const int i = min(lane + k * 64, N_HALO - 1);
+            const int gy = ty0 + i / (T + 2) - 1, gx = tx0 + i % (T + 2) - 1;
+            hv[k] = dist[base + (size_t)min(max(gy, 0), d.H - 1) * d.W + min(max(gx, 0), d.W - 1)];
+        }
+        uint32_t mv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            mv[r] = rmask[base + (size_t)min(ty0 + 16 * h + r, d.H - 1) * d.W + min(tx0 + lx, d.W - 1)];
+        if (lane == 0) flag_in[tile] = 0;                                  // consumed
+        uint32_t inv_v[4] = {0u, 0u, 0u, 0u}, inv_h[4];                    // bit set = no arc; outside the image: all blocked
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t m = (tx0 + lx < d.W && ty0 + 16 * h + r < d.H) ? (~mv[r] & 0xffu) : 0xffu;
+            sm[(16 * h + r) * T + lx] = (uint8_t)m;
+            inv_v[r >> 2] |= m << (8 * (r & 3));
+        }
+#pragma unroll
+        for (int k = 0; k < HALO_IT; ++k) {
+            const int i = lane + k * 64;
+            const int gy = ty0 + i / (T + 2) - 1, gx = tx0 + i % (T + 2) - 1;
+            if (i < N_HALO) sd[i] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? hv[k] : DINF;
+        }
+        mf_wave_sync();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) inv_h[k] = S.m[lx][4 * h + k];         // H sweep: row lx, columns 16h .. 16h+15
+        int old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = S.d[16 * h + r + 1][lx + 1];
+        bool settled = false;
+        for (int it = 0; it < 4 * T; ++it) {                               // a sweep pair that changes nothing: fixpoint
+            const int ch = (it & 1) ? relax_sweep_h(S, inv_h, lx, h) : relax_sweep_v(S, inv_v, lx, h);
+            mf_wave_sync();
+            if (!__any(ch)) { settled = true; break; }
+        }
+        int nbm = settled ? 0 : 1 << 4;                                    // bit (dy + 1) * 3 + (dx + 1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ly = 16 * h + r;
+            const int v = S.d[ly + 1][lx + 1];
+            if (v != old[r]) {
+                dist[base + (size_t)(ty0 + ly) * d.W + tx0 + lx] = v;
+                const int Lf = lx == 0, Rt = lx == T - 1, U = ly == 0, D = ly == T - 1;
+                nbm |= (U & Lf) | U << 1 | (U & Rt) << 2 | Lf << 3 | Rt << 5 | (D & Lf) << 6 | D << 7 | (D & Rt) << 8;
+            }
+        }
+        nbm = mf_wave_or(nbm);
+        if (lane < 9 && (nbm >> lane) & 1) {
+            const int ty = tyi + lane / 3 - 1, tx = txi + lane % 3 - 1;
+            if (ty >= 0 && ty < tl.rt_y && tx >= 0 && tx < tl.rt_x)
+                push_tile(b * tiles_per_image + ty * tl.rt_x + tx, flag_out, list_out, n_out);
+        }
+        mf_wave_sync();
     }
 }
 
@@ -445,6 +535,9 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
         const size_t scale = std::max<size_t>(1, ((size_t)n_cur + 32) / 64);
         const int rl_grid = (int)std::min<size_t>(RELAX_GRID * scale, std::max<size_t>(64, (size_t)n_cur * tl.rt_x * tl.rt_y));
         const int pr_grid = (int)std::min<size_t>(PUSH_GRID * scale, std::max<size_t>(64, (size_t)n_cur * tl.pt_x * tl.pt_y / 2));
+        static const bool relax_wave = RT == MF_RT && env_int("GGC_MF_RELAX_WAVE", 2) == 2;      // 1: the block-per-tile kernel
+        static const int rlw_cap = env_int("GGC_MF_RELAXW_GRID", 1024);
+        const int rlw_grid = (int)std::min<size_t>(rlw_cap * scale, std::max<size_t>(16, cdiv((size_t)n_cur * tl.rt_x * tl.rt_y, 4)));
         // ---- global relabel of the open images
         int relax_launches = 0;
         {
@@ -456,9 +549,14 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
                                rl_list[0], rl_flag[0], rl_cnt);
             int phase = 0;
             for (int guard = 0; guard < 100000; ++guard) {
-                for (int rep = 0; rep < relax_rep; ++rep, ++phase)
-                    hipLaunchKernelGGL(k_mf_relax_list, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
-                                       rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
+                for (int rep = 0; rep < relax_rep; ++rep, ++phase) {
+                    if (relax_wave)
+                        hipLaunchKernelGGL(k_mf_relax_wave, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
+                                           rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
+                    else
+                        hipLaunchKernelGGL(k_mf_relax_list, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
+                                           rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
+                }
                 GGC_LAUNCH_CHECK(ctx);
                 relax_launches = phase;
                 if ((rcode = read_i32(ctx, st, rl_cnt + phase % 3, 1, host))) return rcode;   // size of the next frontier

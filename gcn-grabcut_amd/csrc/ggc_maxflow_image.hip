@@ -24,6 +24,7 @@
 // pass (excess, residual capacities, labels of the halo) is loaded with sc1 (L2-served) loads; every pass boundary
 // is a workgroup barrier followed by an agent-scope acquire (L1 invalidate), after which plain loads are fresh.
 #include "ggc_gc.h"
+#include "ggc_mf_sweep.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -43,11 +44,12 @@ struct PushLds { int ex[PT_N]; int sk[PT_N]; int d[PT_H + 2][PT_W + 2]; int rc[8
 struct RelaxLds { int d[RT + 2][RT + 2]; uint32_t m[RT][RT / 4]; int o[RT][RT]; };
 union WaveLds { PushLds push; RelaxLds relax; };
 struct ImgLds {
-    WaveLds w[MW];
     uint32_t bm[BM_WORDS];          // tiles on the NEXT list
     int wsum[4];
-    int n_list, head, active;
+    int n_list, head, active, pad;
+    WaveLds w[MW];                  // last: a launch with fewer waves (the push-only tail) allocates only its own slices
 };
+static size_t img_lds_bytes(int waves) { return offsetof(ImgLds, w) + (size_t)waves * sizeof(WaveLds); }
 
 // in-kernel stamps of the trace build (GGC_MF_TRACE): wall_clock64 ticks at 100 MHz
 struct VisitProf { long long load = 0, sweep = 0, wb = 0; int sweeps = 0, active = 0; };
@@ -110,15 +112,16 @@ __device__ void relabel_init(const GcDims& d, const MfTiles& tl, size_t base, co
                                                        int32_t* __restrict__ dist, uint32_t* bm, int tid) {
     const int lane = tid & 63;
     constexpr int U = 4;                                   // pixels per thread and trip: U loads in flight
-    const int qw = MT / d.W, rw = MT % d.W;
+    const int mt = blockDim.x;
+    const int qw = mt / d.W, rw = mt % d.W;
     int y = tid / d.W, x = tid % d.W;
-    for (int p0 = tid; p0 < d.P; p0 += U * MT) {
+    for (int p0 = tid; p0 < d.P; p0 += U * mt) {
         int s[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) s[u] = snk[base + min(p0 + u * MT, d.P - 1)];
+        for (int u = 0; u < U; ++u) s[u] = snk[base + min(p0 + u * mt, d.P - 1)];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int p = p0 + u * MT;
+            const int p = p0 + u * mt;
             if (p < d.P) dist[base + p] = s[u] > 0 ? 1 : DINF;
             flag_tile_run(bm, p < d.P && s[u] <= 0, (y / RT) * tl.rt_x + x / RT, lane);
             x += rw; y += qw;
@@ -127,90 +130,8 @@ __device__ void relabel_init(const GcDims& d, const MfTiles& tl, size_t base, co
     }
 }
 
-// ---- relabel tile visit -----------------------------------------------------------------------------------------
-// d(p) = 1 + min over residual arcs p -> q of d(q), relaxed to the tile's fixpoint against a fixed halo.  A sweep where
-// every pixel looks at its 8 neighbours once moves the BFS front one pixel (32+ sweeps per tile, each a chain of LDS round
-// trips).  Here a lane owns 16 consecutive pixels of one column (V sweep) or of one row (H sweep): it reads its 18x3
-// window in one batch, runs a forward and a backward pass over its pixels IN REGISTERS (a front travels the whole
-// segment in one pass), and stores what changed.  Alternating V and H sweeps carry a front across the tile in a
-// handful of sweeps; the arithmetic is branch-free (a missing arc ORs the "infinite" bit into the neighbour's label).
-__device__ __forceinline__ int gated(int v, uint32_t inv, int bit) {        // v if the arc exists, >= DINF otherwise
-    return (__builtin_amdgcn_sbfe((int)inv, bit, 1) & DINF) | v;
-}
-__device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
-__device__ __forceinline__ int relax_px(int c, uint32_t inv, int pos, int lf, int rt, int up, int dn, int ul, int dr, int ur, int dl) {
-    const int nd = min3i(min3i(gated(lf, inv, pos), gated(rt, inv, pos + 1), gated(up, inv, pos + 2)),
-                         min3i(gated(dn, inv, pos + 3), gated(ul, inv, pos + 4), gated(dr, inv, pos + 5)),
-                         min(gated(ur, inv, pos + 6), gated(dl, inv, pos + 7)));
-    return min(c, nd + 1);
-}
+typedef RelaxLds RelaxTile;                          // labels + halo, inverted arc masks (1 byte per pixel); sweeps: ggc_mf_sweep.h
 
-typedef RelaxLds RelaxTile;                          // labels + halo, inverted arc masks (1 byte per pixel)
-
-// lane = (column lx, half h): pixels (rows 16h .. 16h+15, column lx).  Returns 1 when a label changed.
-__device__ __forceinline__ int relax_sweep_v(RelaxTile& S, const uint32_t (&inv_in)[4], int lx, int h) {
-    // the per-arc gate words are loop invariants of the caller's sweep loop: hide the masks from the optimiser, or it hoists
-    // 128 of them out of the loop and spills
-    uint32_t inv[4] = {inv_in[0], inv_in[1], inv_in[2], inv_in[3]};
-    asm volatile("" : "+v"(inv[0]), "+v"(inv[1]), "+v"(inv[2]), "+v"(inv[3]));
-    int w[18][3];
-#pragma unroll
-    for (int a = 0; a < 18; ++a)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) w[a][c] = S.d[16 * h + a][lx + c];
-    uint32_t chg = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int a = r + 1;
-        const int nv = relax_px(w[a][1], inv[r >> 2], 8 * (r & 3), w[a][0], w[a][2], w[a - 1][1], w[a + 1][1], w[a - 1][0], w[a + 1][2],
-                                w[a - 1][2], w[a + 1][0]);
-        chg |= (nv != w[a][1]) ? 1u << r : 0u;
-        w[a][1] = nv;
-    }
-#pragma unroll
-    for (int r = 15; r >= 0; --r) {
-        const int a = r + 1;
-        const int nv = relax_px(w[a][1], inv[r >> 2], 8 * (r & 3), w[a][0], w[a][2], w[a - 1][1], w[a + 1][1], w[a - 1][0], w[a + 1][2],
-                                w[a - 1][2], w[a + 1][0]);
-        chg |= (nv != w[a][1]) ? 1u << r : 0u;
-        w[a][1] = nv;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        if ((chg >> r) & 1u) S.d[16 * h + r + 1][lx + 1] = w[r + 1][1];
-    return chg != 0u;
-}
-// lane = (row ly, half h): pixels (row ly, columns 16h .. 16h+15)
-__device__ __forceinline__ int relax_sweep_h(RelaxTile& S, const uint32_t (&inv_in)[4], int ly, int h) {
-    uint32_t inv[4] = {inv_in[0], inv_in[1], inv_in[2], inv_in[3]};
-    asm volatile("" : "+v"(inv[0]), "+v"(inv[1]), "+v"(inv[2]), "+v"(inv[3]));
-    int w[3][18];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int c = 0; c < 18; ++c) w[a][c] = S.d[ly + a][16 * h + c];
-    uint32_t chg = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int c = k + 1;
-        const int nv = relax_px(w[1][c], inv[k >> 2], 8 * (k & 3), w[1][c - 1], w[1][c + 1], w[0][c], w[2][c], w[0][c - 1], w[2][c + 1],
-                                w[0][c + 1], w[2][c - 1]);
-        chg |= (nv != w[1][c]) ? 1u << k : 0u;
-        w[1][c] = nv;
-    }
-#pragma unroll
-    for (int k = 15; k >= 0; --k) {
-        const int c = k + 1;
-        const int nv = relax_px(w[1][c], inv[k >> 2], 8 * (k & 3), w[1][c - 1], w[1][c + 1], w[0][c], w[2][c], w[0][c - 1], w[2][c + 1],
-                                w[0][c + 1], w[2][c - 1]);
-        chg |= (nv != w[1][c]) ? 1u << k : 0u;
-        w[1][c] = nv;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-        if ((chg >> k) & 1u) S.d[ly + 1][16 * h + k + 1] = w[1][k + 1];
-    return chg != 0u;
-}
 
 // one visit of a 32x32 relabel tile by one wave: relax to the local fixpoint, write back, flag neighbours whose halo changed
 template <bool PROF>
@@ -334,15 +255,16 @@ __device__ void scan_active(const GcDims& d, const MfTiles& tl, size_t base, con
                                                       const int32_t* __restrict__ dist, uint32_t* bm, int* active, int tid) {
     const int lane = tid & 63;
     constexpr int U = 4;
-    const int qw = MT / d.W, rw = MT % d.W;
+    const int mt = blockDim.x;
+    const int qw = mt / d.W, rw = mt % d.W;
     int y = tid / d.W, x = tid % d.W, n = 0;
-    for (int p0 = tid; p0 < d.P; p0 += U * MT) {
+    for (int p0 = tid; p0 < d.P; p0 += U * mt) {
         int e[U], dd[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int pc = min(p0 + u * MT, d.P - 1); e[u] = ex[base + pc]; dd[u] = dist[base + pc]; }
+        for (int u = 0; u < U; ++u) { const int pc = min(p0 + u * mt, d.P - 1); e[u] = ex[base + pc]; dd[u] = dist[base + pc]; }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool a = p0 + u * MT < d.P && e[u] > 0 && dd[u] < DINF;
+            const bool a = p0 + u * mt < d.P && e[u] > 0 && dd[u] < DINF;
             flag_tile_run(bm, a, (y / PT_H) * tl.pt_x + x / PT_W, lane);
             n += a ? 1 : 0;
             x += rw; y += qw;
@@ -637,7 +559,13 @@ int maxflow_image(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* 
                                env_int("GGC_MFI_TAIL_ACTIVE", 256), env_int("GGC_MFI_TAIL_PASSES", 16),
                                env_int("GGC_MFI_TAIL_INNER", 32), 4096, 0};
     Sched sc = sc_full;
-    if (push_passes > 0) { sc.push_only = 1; sc.tail_passes = push_passes; sc.tail_inner = push_inner; }
+    int waves = MW;
+    if (push_passes > 0) {
+        // fewer waves (4 = 50 KB of LDS) would leave the CU to the other lanes' kernels, but the per-image scans then take
+        // three times as long: measured 95 ms per GrabCut stage with 4 waves against 79 with 12 (and 73 without this tail)
+        static const int tail_waves = std::min(MW, std::max(4, env_int("GGC_MF_IMAGE_TAIL_WAVES", MW)));
+        sc.push_only = 1; sc.tail_passes = push_passes; sc.tail_inner = push_inner; waves = tail_waves;
+    }
     int32_t* stats = nullptr;
     static const bool trace = std::getenv("GGC_MF_TRACE") != nullptr;
     if (trace) {
@@ -648,10 +576,10 @@ int maxflow_image(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* 
     {
         ProfScope prof(ctx, st, "maxflow_image");
         if (trace)
-            hipLaunchKernelGGL(k_mf_image<true>, dim3(d.B), dim3(MT), sizeof(ImgLds), st, d, tl, sc, state, rc, ex, snk, dist, rmask,
+            hipLaunchKernelGGL(k_mf_image<true>, dim3(d.B), dim3(waves * 64), img_lds_bytes(waves), st, d, tl, sc, state, rc, ex, snk, dist, rmask,
                                lists, stride, err_flag, stats);
         else
-            hipLaunchKernelGGL(k_mf_image<false>, dim3(d.B), dim3(MT), sizeof(ImgLds), st, d, tl, sc, state, rc, ex, snk, dist, rmask,
+            hipLaunchKernelGGL(k_mf_image<false>, dim3(d.B), dim3(waves * 64), img_lds_bytes(waves), st, d, tl, sc, state, rc, ex, snk, dist, rmask,
                                lists, stride, err_flag, stats);
     }
     GGC_LAUNCH_CHECK(ctx);

@@ -1,0 +1,104 @@
+// ggc_mf_sweep.h — in-register relabel sweeps over a 32x32 tile of labels + halo in LDS, shared by the max-flow drivers
+// (ggc_maxflow.hip: work lists of the whole batch; ggc_maxflow_image.hip: one workgroup per image).
+#pragma once
+#include "ggc_gc.h"
+
+namespace ggc {
+
+__device__ __forceinline__ void mf_wave_sync() {     // LDS traffic of one wave is in order: only the compiler needs telling
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int mf_wave_or(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- relabel tile visit -----------------------------------------------------------------------------------------
+// d(p) = 1 + min over residual arcs p -> q of d(q), relaxed to the tile's fixpoint against a fixed halo.  A sweep where
+// every pixel looks at its 8 neighbours once moves the BFS front one pixel (32+ sweeps per tile, each a chain of LDS round
+// trips).  Here a lane owns 16 consecutive pixels of one column (V sweep) or of one row (H sweep): it reads its 18x3
+// window in one batch, runs a forward and a backward pass over its pixels IN REGISTERS (a front travels the whole
+// segment in one pass), and stores what changed.  Alternating V and H sweeps carry a front across the tile in a
+// handful of sweeps; the arithmetic is branch-free (a missing arc ORs the "infinite" bit into the neighbour's label).
+__device__ __forceinline__ int gated(int v, uint32_t inv, int bit) {        // v if the arc exists, >= DINF otherwise
+    return (__builtin_amdgcn_sbfe((int)inv, bit, 1) & DINF) | v;
+}
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
+__device__ __forceinline__ int relax_px(int c, uint32_t inv, int pos, int lf, int rt, int up, int dn, int ul, int dr, int ur, int dl) {
+    const int nd = min3i(min3i(gated(lf, inv, pos), gated(rt, inv, pos + 1), gated(up, inv, pos + 2)),
+                         min3i(gated(dn, inv, pos + 3), gated(ul, inv, pos + 4), gated(dr, inv, pos + 5)),
+                         min(gated(ur, inv, pos + 6), gated(dl, inv, pos + 7)));
+    return min(c, nd + 1);
+}
+
+
+// lane = (column lx, half h): pixels (rows 16h .. 16h+15, column lx).  Returns 1 when a label changed.
+template <class RelaxTile>
+__device__ __forceinline__ int relax_sweep_v(RelaxTile& S, const uint32_t (&inv_in)[4], int lx, int h) {
+    // the per-arc gate words are loop invariants of the caller's sweep loop: hide the masks from the optimiser, or it hoists
+    // 128 of them out of the loop and spills
+    uint32_t inv[4] = {inv_in[0], inv_in[1], inv_in[2], inv_in[3]};
+    asm volatile("" : "+v"(inv[0]), "+v"(inv[1]), "+v"(inv[2]), "+v"(inv[3]));
+    int w[18][3];
+#pragma unroll
+    for (int a = 0; a < 18; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w[a][c] = S.d[16 * h + a][lx + c];
+    uint32_t chg = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int a = r + 1;
+        const int nv = relax_px(w[a][1], inv[r >> 2], 8 * (r & 3), w[a][0], w[a][2], w[a - 1][1], w[a + 1][1], w[a - 1][0], w[a + 1][2],
+                                w[a - 1][2], w[a + 1][0]);
+        chg |= (nv != w[a][1]) ? 1u << r : 0u;
+        w[a][1] = nv;
+    }
+#pragma unroll
+    for (int r = 15; r >= 0; --r) {
+        const int a = r + 1;
+        const int nv = relax_px(w[a][1], inv[r >> 2], 8 * (r & 3), w[a][0], w[a][2], w[a - 1][1], w[a + 1][1], w[a - 1][0], w[a + 1][2],
+                                w[a - 1][2], w[a + 1][0]);
+        chg |= (nv != w[a][1]) ? 1u << r : 0u;
+        w[a][1] = nv;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if ((chg >> r) & 1u) S.d[16 * h + r + 1][lx + 1] = w[r + 1][1];
+    return chg != 0u;
+}
+// lane = (row ly, half h): pixels (row ly, columns 16h .. 16h+15)
+template <class RelaxTile>
+__device__ __forceinline__ int relax_sweep_h(RelaxTile& S, const uint32_t (&inv_in)[4], int ly, int h) {
+    uint32_t inv[4] = {inv_in[0], inv_in[1], inv_in[2], inv_in[3]};
+    asm volatile("" : "+v"(inv[0]), "+v"(inv[1]), "+v"(inv[2]), "+v"(inv[3]));
+    int w[3][18];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 18; ++c) w[a][c] = S.d[ly + a][16 * h + c];
+    uint32_t chg = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = k + 1;
+        const int nv = relax_px(w[1][c], inv[k >> 2], 8 * (k & 3), w[1][c - 1], w[1][c + 1], w[0][c], w[2][c], w[0][c - 1], w[2][c + 1],
+                                w[0][c + 1], w[2][c - 1]);
+        chg |= (nv != w[1][c]) ? 1u << k : 0u;
+        w[1][c] = nv;
+    }
+#pragma unroll
+    for (int k = 15; k >= 0; --k) {
+        const int c = k + 1;
+        const int nv = relax_px(w[1][c], inv[k >> 2], 8 * (k & 3), w[1][c - 1], w[1][c + 1], w[0][c], w[2][c], w[0][c - 1], w[2][c + 1],
+                                w[0][c + 1], w[2][c - 1]);
+        chg |= (nv != w[1][c]) ? 1u << k : 0u;
+        w[1][c] = nv;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if ((chg >> k) & 1u) S.d[ly + 1][16 * h + k + 1] = w[1][k + 1];
+    return chg != 0u;
+}
+
+} // namespace ggc
