@@ -26,7 +26,7 @@ enum Slot : int {
     S_G_EDGE_ATTR, S_G_PTR, S_G_PRIOR, S_G_AUX, S_G_AUX2, S_G_AUX3, S_G_X,
     S_T_A, S_T_B, S_T_C,
     S_GC_A, S_GC_B, S_GC_C, S_GC_D, S_GC_E, S_GC_F, S_GC_G, S_GC_H, S_GC_I, S_GC_J,
-    S_GC_K, S_GC_L, S_GC_M, S_GC_N,
+    S_GC_K, S_GC_L, S_GC_M, S_GC_N, S_GC_O,
     S_CC_A, S_CC_B, S_CC_C,
     S_MISC_A, S_MISC_B,
     S_COUNT

@@ -491,6 +491,10 @@ static int env_int(const char* name, int dflt) {
     const char* e = std::getenv(name);
     return e ? std::max(1, std::atoi(e)) : dflt;
 }
+static int env_int0(const char* name, int dflt) {       // zero allowed (switches)
+    const char* e = std::getenv(name);
+    return e ? std::max(0, std::atoi(e)) : dflt;
+}
 
 int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
             int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists /*[2B] open-image lists*/,
@@ -510,6 +514,22 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     int32_t *rl_list[2] = {rl, rl + n_rt}, *rl_flag[2] = {rl + 2 * n_rt, rl + 3 * n_rt};
     int32_t *pt_list[2] = {pt, pt + n_pt}, *pt_flag[2] = {pt + 2 * n_pt, pt + 3 * n_pt};
     int32_t *list_cur = lists, *list_nxt = lists + B;
+    // asynchronous single-launch drivers of the sparse phases (ggc_maxflow_async.hip): ring of the larger tile count, the
+    // queue words, one lock word per push tile
+    static const int async_relax = env_int0("GGC_MF_ASYNC_RELAX", 1), relax_dense = env_int0("GGC_MF_RELAX_DENSE", 2);
+    static const int async_push_active = env_int0("GGC_MF_ASYNC_PUSH_ACTIVE", 20000), async_gen = env_int("GGC_MF_ASYNC_GEN", 32);
+    static const int async_inner = env_int("GGC_MF_ASYNC_INNER", 12), async_grid = env_int("GGC_MF_ASYNC_GRID", 128);
+    static const int async_th = env_int("GGC_MF_ASYNC_TH", 8);
+    const size_t ring_cap = std::max(n_rt, n_pt);
+    unsigned long long* ring = nullptr;
+    int32_t *aq = nullptr, *busy = nullptr;
+    if (async_relax || async_push_active > 0) {
+        GGC_REQUIRE(ctx, ring_cap < (1u << 24), GGC_E_UNSUPPORTED, "batch has more max-flow tiles than a queue entry addresses");
+        ring = scratch_t<unsigned long long>(ctx, S_GC_O, ring_cap + (AQ_WORDS + n_pt + 1) / 2 + 1);
+        if (!ring) return GGC_E_OOM;
+        aq = reinterpret_cast<int32_t*>(ring + ring_cap);
+        busy = aq + AQ_WORDS;
+    }
     std::vector<int32_t> host;
     GGC_HIP(ctx, hipMemsetAsync(n_open, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_open_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, list_cur, n_open);
@@ -548,6 +568,18 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             hipLaunchKernelGGL(k_mf_list_all, dim3(cdiv((size_t)n_cur * per_image, 256)), dim3(256), 0, st, n_cur, list_cur, per_image,
                                rl_list[0], rl_flag[0], rl_cnt);
             int phase = 0;
+            if (async_relax && relax_wave) {
+                // the first launches relax every tile of the open images (bandwidth work, plain stores); the long sparse rest of
+                // the front runs asynchronously inside one launch that ends at the fixpoint: nothing to read back
+                for (; phase < relax_dense; ++phase)
+                    hipLaunchKernelGGL(k_mf_relax_wave, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
+                                       rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
+                const int grid = (int)std::min<size_t>(async_grid * scale, std::max<size_t>(16, cdiv((size_t)n_cur * tl.rt_x * tl.rt_y, 16)));
+                if ((rcode = maxflow_relax_async(ctx, st, d, tl, rmask, dist, rl_cnt + phase % 3, rl_list[phase & 1], rl_flag[phase & 1], ring, aq,
+                                                 (int)n_rt, grid, err_flag)))
+                    return rcode;
+                relax_launches = phase + 1;
+            } else
             for (int guard = 0; guard < 100000; ++guard) {
                 for (int rep = 0; rep < relax_rep; ++rep, ++phase) {
                     if (relax_wave)
@@ -619,6 +651,18 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
                 hipLaunchKernelGGL(k_open_state, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, B, n_cur, list_cur, st2);
                 GGC_LAUNCH_CHECK(ctx);
                 if ((rcode = maxflow_image(ctx, st, d, st2, rc, ex, snk, dist, rmask, err_flag, img_tail_passes, img_tail_inner))) return rcode;
+                continue;
+            }
+            if (round > 0 && total_active <= async_push_active) {
+                // sparse round: one asynchronous launch chases the excess from tile to tile (chains of at most async_gen hops)
+                const int waves = (int)std::min<long long>(4ll * async_grid * (long long)scale, std::max<long long>(64, total_active / 4));
+                if ((rcode = maxflow_push_async(ctx, st, d, tl, async_th, async_inner, async_gen, rc, ex, snk, dist, pr_cnt, pt_list[0], (int)n_pt,
+                                                busy, ring, aq, waves, err_flag)))
+                    return rcode;
+                if (trace) {
+                    GGC_HIP(ctx, hipStreamSynchronize(st));
+                    push_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
+                }
                 continue;
             }
             const int launches = tail ? tail_launch : (round == 0 ? n_launch0 : n_launch);
