@@ -54,7 +54,12 @@ __device__ __forceinline__ void push_tile(int tile, int32_t* __restrict__ flag, 
     if (ld(&flag[tile]) == 0 && atomicExch(&flag[tile], 1) == 0) list[atomicAdd(count, 1)] = tile;   // cheap test first
 }
 
-// start of a global relabel: d = 1 next to the sink, infinity elsewhere; rmask bit dir = residual arc p -> nb(dir)
+// start of a global relabel: d = 1 next to the sink, infinity elsewhere.  rmask bit dir = residual arc p -> nb(dir): written by
+// k_build_graph and kept current by every push visit for the pixels it owns (the arcs that LEAVE a 32x8 push tile can be
+// re-opened by the neighbouring tile's pushes, so the relabel kernels read those from the capacities themselves), which
+// spares this pass the 8 capacity planes (41 -> 8 bytes per pixel; 26 GB per 256-image step before).  REBUILD: the masks
+// are recomputed here, for the block-per-tile relabel kernel that takes them as they are.
+template <bool REBUILD>
 __global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __restrict__ open_list, const int32_t* __restrict__ snk,
                                                   const int32_t* __restrict__ rc, int32_t* __restrict__ dist,
                                                   uint8_t* __restrict__ rmask) {
@@ -63,10 +68,12 @@ __global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __res
     if (p >= d.P) return;
     const size_t i = (size_t)open_list[blockIdx.y] * d.P + p;
     dist[i] = snk[i] > 0 ? 1 : DINF;
-    int m = 0;
+    if (REBUILD) {
+        int m = 0;
 #pragma unroll
-    for (int dir = 0; dir < 8; ++dir) m |= (rc[(size_t)dir * BP + i] > 0) ? (1 << dir) : 0;
-    rmask[i] = (uint8_t)m;
+        for (int dir = 0; dir < 8; ++dir) m |= (rc[(size_t)dir * BP + i] > 0) ? (1 << dir) : 0;
+        rmask[i] = (uint8_t)m;
+    }
 }
 
 // every relabel tile of every open image starts on the frontier
@@ -193,7 +200,7 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
 // sweeps where the neighbour-at-a-time iteration above needs one per pixel of the way.  32x32 tiles only.
 struct RelaxWaveLds { int d[MF_RT + 2][MF_RT + 2]; uint32_t m[MF_RT][MF_RT / 4]; };
 __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int phase, const uint8_t* __restrict__ rmask,
-                                                       int32_t* __restrict__ dist, int32_t* __restrict__ counters,
+                                                       const int32_t* __restrict__ rc, int32_t* __restrict__ dist, int32_t* __restrict__ counters,
                                                        const int32_t* __restrict__ list_in, int32_t* __restrict__ list_out,
                                                        int32_t* __restrict__ flag_in, int32_t* __restrict__ flag_out) {
     constexpr int T = MF_RT, N_HALO = (T + 2) * (T + 2), HALO_IT = (N_HALO + 63) / 64;
@@ -214,7 +221,7 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
         const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
         const int tyi = tr / tl.rt_x, txi = tr % tl.rt_x;
         const int tx0 = txi * T, ty0 = tyi * T;
-        const size_t base = (size_t)b * d.P;
+        const size_t base = (size_t)b * d.P, BP = (size_t)d.B * d.P;
         const int lx = lane & 31, h = lane >> 5;
         int hv[HALO_IT];
 #pragma unroll
@@ -227,13 +234,14 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             mv[r] = rmask[base + (size_t)min(ty0 + 16 * h + r, d.H - 1) * d.W + min(tx0 + lx, d.W - 1)];
+        MfBorderArcs ba;
+        ba.load(d, rc, BP, base, ty0, tx0, lx, h);
         if (lane == 0) flag_in[tile] = 0;                                  // consumed
         uint32_t inv_v[4] = {0u, 0u, 0u, 0u}, inv_h[4];                    // bit set = no arc; outside the image: all blocked
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const uint32_t m = (tx0 + lx < d.W && ty0 + 16 * h + r < d.H) ? (~mv[r] & 0xffu) : 0xffu;
+            const uint32_t m = (tx0 + lx < d.W && ty0 + 16 * h + r < d.H) ? ba.row(~mv[r] & 0xffu, r) : 0xffu;
             sm[(16 * h + r) * T + lx] = (uint8_t)m;
-            inv_v[r >> 2] |= m << (8 * (r & 3));
         }
 #pragma unroll
         for (int k = 0; k < HALO_IT; ++k) {
@@ -242,6 +250,10 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
             if (i < N_HALO) sd[i] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? hv[k] : DINF;
         }
         mf_wave_sync();
+        if (ty0 + lx < d.H && tx0 + (h ? 31 : 0) < d.W) sm[lx * T + (h ? 31 : 0)] = (uint8_t)ba.col(sm[lx * T + (h ? 31 : 0)], h);
+        mf_wave_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) inv_v[r >> 2] |= (uint32_t)sm[(16 * h + r) * T + lx] << (8 * (r & 3));
 #pragma unroll
         for (int k = 0; k < 4; ++k) inv_h[k] = S.m[lx][4 * h + k];         // H sweep: row lx, columns 16h .. 16h+15
         int old[16];
@@ -280,7 +292,7 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
 template <int PPT>
 __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl, int phase, int inner,
                                                           int32_t* __restrict__ rc, int32_t* __restrict__ ex,
-                                                          int32_t* __restrict__ snk, int32_t* __restrict__ dist,
+                                                          int32_t* __restrict__ snk, int32_t* __restrict__ dist, uint8_t* __restrict__ rmask,
                                                           int32_t* __restrict__ counters, const int32_t* __restrict__ list_in,
                                                           int32_t* __restrict__ list_out, int32_t* __restrict__ flag_in,
                                                           int32_t* __restrict__ flag_out) {
@@ -420,14 +432,18 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
             const bool ring = lx == 0 || lx == PT_W - 1 || ly == 0 || ly == PT_H - 1;
             const int e1 = s_ex[slot];
             if (e1 != e0[j]) { if (ring) atomicAdd(&ex[base + p], e1 - e0[j]); else ex[base + p] = e1; }
+            int m1 = 0, chg = 0;
 #pragma unroll
             for (int dir = 0; dir < 8; ++dir) {
                 const int r1 = s_rc[dir][slot];
+                m1 |= (r1 > 0) ? (1 << dir) : 0;
                 if (r1 != r0[j][dir]) {
+                    chg = 1;
                     if (ring) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[j][dir]);
                     else rc[(size_t)dir * BP + base + p] = r1;
                 }
             }
+            if (chg) rmask[base + p] = (uint8_t)m1;     // (arcs that leave the tile: the relabel reads the capacities, see k_mf_dinit)
             if (sk[j] != sk0[j]) snk[base + p] = sk[j];
             const int d1 = s_d[ly + 1][lx + 1];
             if (d1 != d0[j]) dist[base + p] = d1;
@@ -562,7 +578,8 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
         int relax_launches = 0;
         {
             ProfScope prof(ctx, st, "maxflow_relabel");
-            hipLaunchKernelGGL(k_mf_dinit, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
+            if (relax_wave) hipLaunchKernelGGL(k_mf_dinit<false>, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
+            else hipLaunchKernelGGL(k_mf_dinit<true>, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
             GGC_HIP(ctx, hipMemsetAsync(rl_flag[0], 0, sizeof(int32_t) * n_rt * 2, st));
             const int per_image = tl.rt_x * tl.rt_y;
             hipLaunchKernelGGL(k_mf_list_all, dim3(cdiv((size_t)n_cur * per_image, 256)), dim3(256), 0, st, n_cur, list_cur, per_image,
@@ -572,10 +589,10 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
                 // the first launches relax every tile of the open images (bandwidth work, plain stores); the long sparse rest of
                 // the front runs asynchronously inside one launch that ends at the fixpoint: nothing to read back
                 for (; phase < relax_dense; ++phase)
-                    hipLaunchKernelGGL(k_mf_relax_wave, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
+                    hipLaunchKernelGGL(k_mf_relax_wave, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, rmask, rc, dist, rl_cnt,
                                        rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
                 const int grid = (int)std::min<size_t>(async_grid * scale, std::max<size_t>(16, cdiv((size_t)n_cur * tl.rt_x * tl.rt_y, 16)));
-                if ((rcode = maxflow_relax_async(ctx, st, d, tl, rmask, dist, rl_cnt + phase % 3, rl_list[phase & 1], rl_flag[phase & 1], ring, aq,
+                if ((rcode = maxflow_relax_async(ctx, st, d, tl, rmask, rc, dist, rl_cnt + phase % 3, rl_list[phase & 1], rl_flag[phase & 1], ring, aq,
                                                  (int)n_rt, grid, err_flag)))
                     return rcode;
                 relax_launches = phase + 1;
@@ -583,7 +600,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             for (int guard = 0; guard < 100000; ++guard) {
                 for (int rep = 0; rep < relax_rep; ++rep, ++phase) {
                     if (relax_wave)
-                        hipLaunchKernelGGL(k_mf_relax_wave, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
+                        hipLaunchKernelGGL(k_mf_relax_wave, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, rmask, rc, dist, rl_cnt,
                                            rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
                     else
                         hipLaunchKernelGGL(k_mf_relax_list, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
@@ -656,7 +673,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             if (round > 0 && total_active <= async_push_active) {
                 // sparse round: one asynchronous launch chases the excess from tile to tile (chains of at most async_gen hops)
                 const int waves = (int)std::min<long long>(4ll * async_grid * (long long)scale, std::max<long long>(64, total_active / 4));
-                if ((rcode = maxflow_push_async(ctx, st, d, tl, async_th, async_inner, async_gen, rc, ex, snk, dist, pr_cnt, pt_list[0], (int)n_pt,
+                if ((rcode = maxflow_push_async(ctx, st, d, tl, async_th, async_inner, async_gen, rc, ex, snk, dist, rmask, pr_cnt, pt_list[0], (int)n_pt,
                                                 busy, ring, aq, waves, err_flag)))
                     return rcode;
                 if (trace) {
@@ -676,10 +693,10 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             static const int ppt = env_int("GGC_MF_PPT", 1);   // 2 measured 3 % slower end to end: the longer visit outweighs the tiles in flight
             for (int phase = 0; phase < launches; ++phase) {
                 if (ppt == 2)
-                    hipLaunchKernelGGL((k_mf_pr_list<2>), dim3(grid), dim3(PT_N / 2), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, pr_cnt,
+                    hipLaunchKernelGGL((k_mf_pr_list<2>), dim3(grid), dim3(PT_N / 2), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, rmask, pr_cnt,
                                        pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
                 else
-                    hipLaunchKernelGGL((k_mf_pr_list<1>), dim3(grid), dim3(PT_N), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, pr_cnt,
+                    hipLaunchKernelGGL((k_mf_pr_list<1>), dim3(grid), dim3(PT_N), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, rmask, pr_cnt,
                                        pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
             }
             GGC_LAUNCH_CHECK(ctx);

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) k_aq_init(const int32_t* __restrict__ cou
 struct RelaxWaveLds { int d[RT + 2][RT + 2]; uint32_t m[RT][RT / 4]; };
 
 __global__ void __launch_bounds__(256) k_mf_relax_async(GcDims d, MfTiles tl, const uint8_t* __restrict__ rmask,
-                                                        int32_t* __restrict__ dist, int32_t* __restrict__ flag,
+                                                        const int32_t* __restrict__ rc, int32_t* __restrict__ dist, int32_t* __restrict__ flag,
                                                         unsigned long long* __restrict__ ring, int32_t* __restrict__ q, int cap,
                                                         int32_t* __restrict__ err_flag) {
     constexpr int T = RT, HALO_IT = (RT_HALO + 63) / 64;
@@ -137,12 +137,13 @@ __global__ void __launch_bounds__(256) k_mf_relax_async(GcDims d, MfTiles tl, co
 #pragma unroll
         for (int r = 0; r < 16; ++r)                                       // arc masks do not change during a relabel: plain loads
             mv[r] = rmask[base + (size_t)min(ty0 + 16 * h + r, d.H - 1) * d.W + min(tx0 + lx, d.W - 1)];
+        MfBorderArcs ba;                                                   // (capacities do not change during a relabel either)
+        ba.load(d, rc, (size_t)d.B * d.P, base, ty0, tx0, lx, h);
         uint32_t inv_v[4] = {0u, 0u, 0u, 0u}, inv_h[4];                    // bit set = no arc; outside the image: all blocked
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const uint32_t m = (tx0 + lx < d.W && ty0 + 16 * h + r < d.H) ? (~mv[r] & 0xffu) : 0xffu;
+            const uint32_t m = (tx0 + lx < d.W && ty0 + 16 * h + r < d.H) ? ba.row(~mv[r] & 0xffu, r) : 0xffu;
             sm[(16 * h + r) * T + lx] = (uint8_t)m;
-            inv_v[r >> 2] |= m << (8 * (r & 3));
         }
 #pragma unroll
         for (int k = 0; k < HALO_IT; ++k) {
@@ -151,6 +152,10 @@ __global__ void __launch_bounds__(256) k_mf_relax_async(GcDims d, MfTiles tl, co
             if (i < RT_HALO) sd[i] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? hv[k] : DINF;
         }
         mf_wave_sync();
+        if (ty0 + lx < d.H && tx0 + (h ? 31 : 0) < d.W) sm[lx * T + (h ? 31 : 0)] = (uint8_t)ba.col(sm[lx * T + (h ? 31 : 0)], h);
+        mf_wave_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) inv_v[r >> 2] |= (uint32_t)sm[(16 * h + r) * T + lx] << (8 * (r & 3));
 #pragma unroll
         for (int k = 0; k < 4; ++k) inv_h[k] = S.m[lx][4 * h + k];         // H sweep: row lx, columns 16h .. 16h+15
         int old[16];
@@ -215,7 +220,7 @@ struct PushTileLds {
 template <int TH>
 __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, size_t base, size_t BP,
                                int32_t* __restrict__ rc, int32_t* __restrict__ ex, int32_t* __restrict__ snk,
-                               int32_t* __restrict__ dist, PushTileLds<TH>& S, int lane) {
+                               int32_t* __restrict__ dist, uint8_t* __restrict__ rmask, PushTileLds<TH>& S, int lane) {
     constexpr int NPX = TH / 2, HALO = (TH + 2) * 34, HALO_IT = (HALO + 63) / 64;
     const int lx = lane & 31, r0 = lane >> 5;
     const int x = txi * 32 + lx;
@@ -351,9 +356,20 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
         // everything returns as an atomic read-modify-write: deltas where a neighbouring tile's wave may have added meanwhile
         // (excess, reverse arcs), exchanges for what only the tile's holder writes (sink link, label)
         if (e1 != e0[j]) atomicAdd(&ex[p], e1 - e0[j]);
+        int m1 = 0, chg = 0;
 #pragma unroll
-        for (int dir = 0; dir < 8; ++dir)
-            if (r1[dir] != r0v[j][dir]) atomicAdd(&rc[(size_t)dir * BP + p], r1[dir] - r0v[j][dir]);
+        for (int dir = 0; dir < 8; ++dir) {
+            m1 |= (r1[dir] > 0) ? (1 << dir) : 0;
+            if (r1[dir] != r0v[j][dir]) { chg = 1; atomicAdd(&rc[(size_t)dir * BP + p], r1[dir] - r0v[j][dir]); }
+        }
+        if (chg) {
+            // read by the next relabel only, but a tile can be visited from several XCDs within this launch: two plain stores to
+            // one byte would sit in two L2s and reach memory in either order.  Atomics on the byte's word (clear, then set).
+            uint32_t* w = reinterpret_cast<uint32_t*>(rmask + (p & ~(size_t)3));
+            const int sh = 8 * (int)(p & 3);
+            atomicAnd(w, ~(0xffu << sh));
+            atomicOr(w, (uint32_t)m1 << sh);
+        }
         if (sk1 != sk0[j]) atomicExch(&snk[p], sk1);
         // the label: compare with the halo copy's origin is not kept, so write when the pixel was relabelled (d only rises here)
         left |= (e1 > 0 && d1 < d.P) ? 1 : 0;
@@ -375,7 +391,7 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
 template <int TH>
 __global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt_y, int inner, int gen_max, int follow, int32_t* __restrict__ rc,
                                                       int32_t* __restrict__ ex, int32_t* __restrict__ snk, int32_t* __restrict__ dist,
-                                                      int32_t* __restrict__ st, unsigned long long* __restrict__ ring,
+                                                      uint8_t* __restrict__ rmask, int32_t* __restrict__ st, unsigned long long* __restrict__ ring,
                                                       int32_t* __restrict__ q, int cap, int32_t* __restrict__ err_flag) {
     __shared__ PushTileLds<TH> S;
     const int tiles_per_image = bt_x * bt_y;
@@ -401,7 +417,7 @@ __global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt
         drain();                                                           // ... before the tile is loaded
         const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
         const int tyi = tr / bt_x, txi = tr % bt_x;
-        const int nbm = push_tile_visit<TH>(d, tyi, txi, inner, (size_t)b * d.P, BP, rc, ex, snk, dist, S, lane);
+        const int nbm = push_tile_visit<TH>(d, tyi, txi, inner, (size_t)b * d.P, BP, rc, ex, snk, dist, rmask, S, lane);
         drain();                                                           // the write-back is at memory
         const bool left = (nbm >> 4) & 1;
         int nb = -1;
@@ -452,17 +468,17 @@ __global__ void __launch_bounds__(256) k_aq_fill_big(const int32_t* __restrict__
 
 } // namespace
 
-int maxflow_relax_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, const uint8_t* rmask, int32_t* dist,
+int maxflow_relax_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, const uint8_t* rmask, const int32_t* rc, int32_t* dist,
                         const int32_t* count, const int32_t* list, int32_t* flag, unsigned long long* ring, int32_t* q, int cap,
                         int grid, int32_t* err_flag) {
     hipLaunchKernelGGL(k_aq_init, dim3(cdiv(cap, 256)), dim3(256), 0, st, count, list, ring, q, cap, 0);
-    hipLaunchKernelGGL(k_mf_relax_async, dim3(grid), dim3(256), 0, st, d, tl, rmask, dist, flag, ring, q, cap, err_flag);
+    hipLaunchKernelGGL(k_mf_relax_async, dim3(grid), dim3(256), 0, st, d, tl, rmask, rc, dist, flag, ring, q, cap, err_flag);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
 }
 
 int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, int th, int inner, int gen_max, int32_t* rc,
-                       int32_t* ex, int32_t* snk, int32_t* dist, const int32_t* count, const int32_t* list, int n_list_max, int32_t* state,
+                       int32_t* ex, int32_t* snk, int32_t* dist, uint8_t* rmask, const int32_t* count, const int32_t* list, int n_list_max, int32_t* state,
                        unsigned long long* ring, int32_t* q, int waves, int32_t* err_flag) {
     th = th >= 32 ? 32 : (th >= 16 ? 16 : 8);
     const int bt_x = tl.pt_x, bt_y = cdiv(d.H, th), cap = bt_x * bt_y * d.B;
@@ -474,13 +490,13 @@ int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTi
     hipLaunchKernelGGL(k_aq_fill_big, dim3(cdiv(n_list_max, 256)), dim3(256), 0, st, count, list, tl.pt_x, tl.pt_y, th, bt_x, bt_y, state, ring, q,
                        gen_max);
     if (th == 32)
-        hipLaunchKernelGGL(k_mf_push_async<32>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<32>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag);
     else if (th == 8)
-        hipLaunchKernelGGL(k_mf_push_async<8>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<8>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag);
     else
-        hipLaunchKernelGGL(k_mf_push_async<16>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<16>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;

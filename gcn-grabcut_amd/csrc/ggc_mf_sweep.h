@@ -34,6 +34,50 @@ __device__ __forceinline__ int relax_px(int c, uint32_t inv, int pos, int lf, in
 }
 
 
+// Arc masks of a 32x32 relabel tile come from rmask (1 byte per pixel, kept current by the push visits for the arcs inside
+// their 32x8 tile).  An arc that LEAVES its pixel's push tile may have been re-opened by a push from the neighbouring tile
+// after the owner wrote the mask, so those bits are taken from the capacities themselves: rows with y % 8 == 0 / 7 (arcs
+// up / down: rows 0, 8 / 7, 15 of the lane's V-sweep segment) and columns 0 / 31 (arcs left / right: the lane's H-sweep
+// pixel of that column).  15 loads per lane.  Masks are INVERTED (bit set = no arc).
+struct MfBorderArcs {
+    int fr[4][3], fc[3];
+    __device__ __forceinline__ void load(const GcDims& d, const int32_t* __restrict__ rc, size_t BP, size_t base, int ty0, int tx0,
+                                         int lx, int h) {
+        const size_t cx = min(tx0 + lx, d.W - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                      // q: rows 0, 7, 8, 15 of the lane's segment
+            const int r = (q >> 1) * 8 + ((q & 1) ? 7 : 0);
+            const size_t i = base + (size_t)min(ty0 + 16 * h + r, d.H - 1) * d.W + cx;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) fr[q][t] = rc[(size_t)((q & 1) ? 3 + 2 * t : 2 + 2 * t) * BP + i];   // 3,5,7 | 2,4,6
+        }
+        const size_t i = base + (size_t)min(ty0 + lx, d.H - 1) * d.W + min(tx0 + (h ? 31 : 0), d.W - 1);   // H-sweep row lx
+        fc[0] = rc[(size_t)(h ? 1 : 0) * BP + i];
+        fc[1] = rc[(size_t)(h ? 5 : 4) * BP + i];
+        fc[2] = rc[(size_t)(h ? 6 : 7) * BP + i];
+    }
+    // inverted mask of row r (0..15) of the lane's segment
+    __device__ __forceinline__ uint32_t row(uint32_t m, int r) const {
+        if ((r & 7) == 0 || (r & 7) == 7) {
+            const int q = (r >> 3) * 2 + ((r & 7) ? 1 : 0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const uint32_t bit = 1u << (((r & 7) ? 3 : 2) + 2 * t);
+                m = (fr[q][t] > 0) ? (m & ~bit) : (m | bit);
+            }
+        }
+        return m;
+    }
+    // inverted mask of the pixel (row lx, column h ? 31 : 0)
+    __device__ __forceinline__ uint32_t col(uint32_t m, int h) const {
+        const uint32_t b0 = 1u << (h ? 1 : 0), b1 = 1u << (h ? 5 : 4), b2 = 1u << (h ? 6 : 7);
+        m = (fc[0] > 0) ? (m & ~b0) : (m | b0);
+        m = (fc[1] > 0) ? (m & ~b1) : (m | b1);
+        m = (fc[2] > 0) ? (m & ~b2) : (m | b2);
+        return m;
+    }
+};
+
 // lane = (column lx, half h): pixels (rows 16h .. 16h+15, column lx).  Returns 1 when a label changed.
 template <class RelaxTile>
 __device__ __forceinline__ int relax_sweep_v(RelaxTile& S, const uint32_t (&inv_in)[4], int lx, int h) {
