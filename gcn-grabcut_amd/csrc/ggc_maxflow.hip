@@ -556,8 +556,8 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     if (n_cur == 0) return GGC_OK;
     const bool trace = std::getenv("GGC_MF_TRACE") != nullptr;
     // schedule measured on MI355X (tools/mf_sweep.sh)
-    static const int n_launch = env_int("GGC_MF_PR_LAUNCHES", 24), n_inner = env_int("GGC_MF_PR_INNER", 8);
-    static const int n_launch0 = env_int("GGC_MF_PR_LAUNCHES0", 12);
+    static const int n_launch = env_int("GGC_MF_PR_LAUNCHES", 12), n_inner = env_int("GGC_MF_PR_INNER", 8);
+    static const int n_launch0 = env_int("GGC_MF_PR_LAUNCHES0", 8);
     static const int relax_rep = env_int("GGC_MF_RELAX_REP", 4);         // relabel launches per read-back of the next list's size
     static const int tail_active = env_int("GGC_MF_TAIL_ACTIVE", 4000), tail_launch = env_int("GGC_MF_TAIL_LAUNCHES", 64);
     const int max_rounds = 4096;
