@@ -383,21 +383,27 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
                 const int dp = s_d[ly + 1][lx + 1];
                 if (e > 0 && dp < d.P) {
                     act = 1;
-                    int hmin = DINF, best = -1;
-                    if (sk[j] > 0) { hmin = 0; best = 8; }
+                    // the 8 residual capacities and 8 neighbour labels are read in one batch and the arg-min is branch-free:
+                    // one LDS round trip per sweep instead of a chain of up to 16
+                    int r[8], hq[8];
 #pragma unroll
-                    for (int dir = 0; dir < 8; ++dir)
-                        if (__hip_atomic_load(&s_rc[dir][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) {
-                            const int hq = s_d[ly + 1 + dir_dy(dir)][lx + 1 + dir_dx(dir)];
-                            if (hq < hmin) { hmin = hq; best = dir; }
-                        }
+                    for (int dir = 0; dir < 8; ++dir) {
+                        r[dir] = __hip_atomic_load(&s_rc[dir][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        hq[dir] = s_d[ly + 1 + dir_dy(dir)][lx + 1 + dir_dx(dir)];
+                    }
+                    int hmin = sk[j] > 0 ? 0 : DINF, best = sk[j] > 0 ? 8 : -1, rb = 0;
+#pragma unroll
+                    for (int dir = 0; dir < 8; ++dir) {
+                        const bool ok = r[dir] > 0 && hq[dir] < hmin;
+                        hmin = ok ? hq[dir] : hmin; best = ok ? dir : best; rb = ok ? r[dir] : rb;
+                    }
                     if (best >= 0 && dp > hmin) {
                         if (best == 8) {
                             const int dl = min(e, sk[j]);
                             sk[j] -= dl;
                             atomicSub(&s_ex[slot], dl);
                         } else {
-                            const int dl = min(e, __hip_atomic_load(&s_rc[best][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            const int dl = min(e, rb);
                             atomicSub(&s_rc[best][slot], dl);
                             atomicSub(&s_ex[slot], dl);
                             const int bx = dir_dx(best), by = dir_dy(best);

@@ -160,7 +160,6 @@ class GCNGrabCutPipeline:
         caller = torch.cuda.current_stream(self._eng.device)
         out: list = [None] * len(batches)
         errors: list = []
-        lanes_before, self.grabcut_lanes = self.grabcut_lanes, 1
 
         def worker(i):
             try:
@@ -168,19 +167,16 @@ class GCNGrabCutPipeline:
                 self._streams[i].wait_stream(caller)               # the batches were produced on the caller's stream
                 with torch.cuda.stream(self._streams[i]):
                     for k in range(i, len(batches), n):
-                        out[k] = pipes[i].segment_batch_device(batches[k], **kwargs)
+                        out[k] = pipes[i].segment_batch_device(batches[k], grabcut_lanes=1, **kwargs)
                 self._streams[i].synchronize()
             except Exception as exc:                               # re-raised in the caller's thread
                 errors.append(exc)
 
         threads = [threading.Thread(target=worker, args=(i,), name=f"ggc-pipe{i}") for i in range(n)]
-        try:
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-        finally:
-            self.grabcut_lanes = lanes_before
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
         if errors:
             raise errors[0]
         for o in out:                                              # the results were allocated on the side streams
@@ -194,7 +190,7 @@ class GCNGrabCutPipeline:
     def segment_batch_device(self, bgr, threshold_fg: float = 0.55, threshold_bg: float = 0.55,
                              refine_iters: int = 0, min_area_ratio: float = 0.002, keep_largest: bool = False,
                              edge_aware: bool = True, filter_radius: int = 8, compose: bool = True,
-                             timing: Optional[dict] = None) -> dict:
+                             timing: Optional[dict] = None, grabcut_lanes: Optional[int] = None) -> dict:
         """bgr: (B,H,W,3) uint8 tensor on the pipeline's device.  Returns device tensors."""
         import torch
         eng, cfg = self._eng, self.sp_config
@@ -229,7 +225,8 @@ class GCNGrabCutPipeline:
 
         t = tick()
         mask = trimap.clone()
-        lanes = self.grabcut_lanes if bgr.size(0) >= 8 * max(self.grabcut_lanes, 1) else 1
+        want = self.grabcut_lanes if grabcut_lanes is None else int(grabcut_lanes)   # (an argument, so that concurrent callers do not mutate the pipeline)
+        lanes = want if bgr.size(0) >= 8 * max(want, 1) else 1
         gc_img = bgr if cs == "rgb" else eng.convert_color8(bgr, cs)      # reference grabcut.py:73-79
         binary, mask, bgd, fgd = eng.grabcut_lanes(gc_img, mask, self.gc_config.n_iter, 0, self.gc_config.seed, lanes)
         if refine_iters > 0:
