@@ -54,6 +54,29 @@ __device__ __forceinline__ void push_tile(int tile, int32_t* __restrict__ flag, 
     if (ld(&flag[tile]) == 0 && atomicExch(&flag[tile], 1) == 0) list[atomicAdd(count, 1)] = tile;   // cheap test first
 }
 
+// The same through a per-block list.  Every append used to be a returning atomicAdd on the ONE counter of the next list, and
+// same-address atomics retire at ~90 per microsecond chip-wide: a dense launch appends ~15 000 tiles, i.e. >= 150 us of
+// counter traffic — which is what those launches took (139-165 us), whatever the grid or the occupancy.  A block now
+// collects its tiles in LDS and reserves their slots with one atomicAdd when it is done.
+constexpr int OUT_CAP = 1024;
+struct OutList { int n, base; int buf[OUT_CAP]; };
+__device__ __forceinline__ void push_tile_l(int tile, int32_t* __restrict__ flag, OutList& L, int32_t* __restrict__ list,
+                                            int32_t* __restrict__ count) {
+    if (ld(&flag[tile]) == 0 && atomicExch(&flag[tile], 1) == 0) {
+        const int i = atomicAdd(&L.n, 1);
+        if (i < OUT_CAP) L.buf[i] = tile;
+        else list[atomicAdd(count, 1)] = tile;                             // (a block that overflows its list appends directly)
+    }
+}
+// all threads of the block, once, after their last push_tile_l
+__device__ __forceinline__ void flush_tiles(OutList& L, int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    __syncthreads();
+    const int n = min(L.n, OUT_CAP);
+    if (threadIdx.x == 0 && n > 0) L.base = atomicAdd(count, n);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) list[L.base + i] = L.buf[i];
+}
+
 // start of a global relabel: d = 1 next to the sink, infinity elsewhere.  rmask bit dir = residual arc p -> nb(dir): written by
 // k_build_graph and kept current by every push visit for the pixels it owns (the arcs that LEAVE a 32x8 push tile can be
 // re-opened by the neighbouring tile's pushes, so the relabel kernels read those from the capacities themselves), which
@@ -205,6 +228,9 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
                                                        int32_t* __restrict__ flag_in, int32_t* __restrict__ flag_out) {
     constexpr int T = MF_RT, N_HALO = (T + 2) * (T + 2), HALO_IT = (N_HALO + 63) / 64;
     __shared__ RelaxWaveLds lds[4];
+    __shared__ OutList outl;
+    if (threadIdx.x == 0) outl.n = 0;
+    __syncthreads();
     const int wv = threadIdx.x >> 6;
     RelaxWaveLds& S = lds[wv];
     const int n_in = counters[phase % 3];
@@ -280,10 +306,11 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
         if (lane < 9 && (nbm >> lane) & 1) {
             const int ty = tyi + lane / 3 - 1, tx = txi + lane % 3 - 1;
             if (ty >= 0 && ty < tl.rt_y && tx >= 0 && tx < tl.rt_x)
-                push_tile(b * tiles_per_image + ty * tl.rt_x + tx, flag_out, list_out, n_out);
+                push_tile_l(b * tiles_per_image + ty * tl.rt_x + tx, flag_out, outl, list_out, n_out);
         }
         mf_wave_sync();
     }
+    flush_tiles(outl, list_out, n_out);
 }
 
 // Push-relabel sweeps over a work list of 32x8 tiles.  PPT pixels per thread: a dense launch is bound by tile visits in
@@ -300,7 +327,10 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
     __shared__ int s_ex[PT_N];
     __shared__ int s_d[PT_H + 2][PT_W + 2];
     __shared__ int s_rc[8][PT_N];
+    __shared__ OutList outl;
+    __shared__ int s_nbm;                                                  // bit (dy + 1) * 3 + (dx + 1): tiles to put on the next list
     const int tid = threadIdx.x, lx = tid & 31;
+    if (tid == 0) outl.n = 0;                                              // (the first barrier of the tile loop orders it)
     const int n_in = counters[phase % 3];
     int32_t* n_out = counters + (phase + 1) % 3;
     if (blockIdx.x == 0 && tid == 0) counters[(phase + 2) % 3] = 0;
@@ -370,9 +400,10 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
             load_tile(tile_next, N);
         }
         __syncthreads();
-        if (tid == 0) flag_in[tile] = 0;                                   // consumed
+        if (tid == 0) { flag_in[tile] = 0; s_nbm = 0; }                                   // consumed
 #pragma unroll
         for (int j = 0; j < PPT; ++j) d0[j] = s_d[((tid + j * NT) >> 5) + 1][lx + 1];
+        int nbm = 0;
         for (int it = 0; it < inner; ++it) {
             int act = 0;
 #pragma unroll
@@ -417,7 +448,9 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
                                 const int y = tyi * PT_H + ly;
                                 atomicAdd(&rc[(size_t)(best ^ 1) * BP + base + q], dl);
                                 atomicAdd(&ex[base + q], dl);
-                                push_tile(b * tiles_per_image + ((y + by) / PT_H) * tl.pt_x + (x + bx) / PT_W, flag_out, list_out, n_out);
+                                // (the neighbour tile is told after the sweeps, see k_mf_pr_wave)
+                                const int tdy = qly < 0 ? -1 : (qly >= PT_H ? 1 : 0), tdx = qlx < 0 ? -1 : (qlx >= PT_W ? 1 : 0);
+                                nbm |= 1 << ((tdy + 1) * 3 + tdx + 1);
                             }
                         }
                     } else {
@@ -445,7 +478,12 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
                 m1 |= (r1 > 0) ? (1 << dir) : 0;
                 if (r1 != r0[j][dir]) {
                     chg = 1;
-                    if (ring) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[j][dir]);
+                    // another tile's push can only add to an arc that points OUT of this tile (the reverse of its own arc):
+                    // those go back as atomic deltas, every other capacity is this block's alone (L2 atomics, ~30 G/s chip-wide,
+                    // are what bounds the dense rounds)
+                    const bool out = (ly == 0 && dir_dy(dir) < 0) || (ly == PT_H - 1 && dir_dy(dir) > 0) ||
+                                     (lx == 0 && dir_dx(dir) < 0) || (lx == PT_W - 1 && dir_dx(dir) > 0);
+                    if (out) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[j][dir]);
                     else rc[(size_t)dir * BP + base + p] = r1;
                 }
             }
@@ -455,8 +493,219 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
             if (d1 != d0[j]) dist[base + p] = d1;
             left |= (e1 > 0 && d1 < d.P) ? 1 : 0;
         }
-        if (__syncthreads_or(left) && tid == 0) push_tile(tile, flag_out, list_out, n_out);   // still has work
+        if (nbm) atomicOr(&s_nbm, nbm);
+        if (__syncthreads_or(left) && tid == 0) s_nbm |= 1 << 4;           // still has work
+        __syncthreads();
+        if (tid < 9 && (s_nbm >> tid) & 1) {
+            const int ty = tyi + tid / 3 - 1, tx = txi + tid % 3 - 1;
+            if (ty >= 0 && ty < tl.pt_y && tx >= 0 && tx < tl.pt_x)
+                push_tile_l(b * tiles_per_image + ty * tl.pt_x + tx, flag_out, outl, list_out, n_out);
+        }
     }
+    flush_tiles(outl, list_out, n_out);
+}
+
+// The same push-relabel sweeps with a WAVE per tile (4 tiles per block, no block barrier).  The block-per-tile kernel above
+// is bound by instruction issue, not by memory or latency: every one of a tile's 4 waves runs the ~120-instruction active
+// path in every sweep as soon as one of its 64 pixels is active, and only ~12 % of the pixels of a visited tile are — a
+// dense launch moved its ~15 000 tiles at ~110 tiles per microsecond whatever the grid, the occupancy or the list-counter
+// traffic (measured).  Here a sweep first compacts the tile's active pixels into an LDS list (ballot + mbcnt) and hands ONE
+// active pixel to each lane: the active path runs once per 64 active pixels instead of once per wave of the tile, about a
+// third of the instructions per visit.  Loads, write-back (interior plain, ring as atomic deltas), arc masks and work lists
+// are those of k_mf_pr_list; 4 pixels per lane.
+struct PushWaveLds { int ex[PT_N]; int sk[PT_N]; int d[PT_H + 2][PT_W + 2]; int rc[8][PT_N]; unsigned short act[PT_N]; };
+
+template <bool PROF>
+__global__ void __launch_bounds__(256) k_mf_pr_wave(GcDims d, MfTiles tl, int phase, int inner, long long* __restrict__ prof,
+                                                    int32_t* __restrict__ rc, int32_t* __restrict__ ex,
+                                                    int32_t* __restrict__ snk, int32_t* __restrict__ dist, uint8_t* __restrict__ rmask,
+                                                    int32_t* __restrict__ counters, const int32_t* __restrict__ list_in,
+                                                    int32_t* __restrict__ list_out, int32_t* __restrict__ flag_in,
+                                                    int32_t* __restrict__ flag_out) {
+    static_assert(PT_W == 32 && PT_N % 64 == 0, "wave-per-tile push kernel: 32-pixel tile rows");
+    constexpr int PX = PT_N / 64, N_HALO = (PT_H + 2) * (PT_W + 2), HALO_IT = (N_HALO + 63) / 64;
+    __shared__ PushWaveLds lds[4];
+    __shared__ OutList outl;
+    if (threadIdx.x == 0) outl.n = 0;
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    PushWaveLds& S = lds[wv];
+    const int n_in = counters[phase % 3];
+    int32_t* n_out = counters + (phase + 1) % 3;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[(phase + 2) % 3] = 0;
+    const int tiles_per_image = tl.pt_x * tl.pt_y;
+    const size_t BP = (size_t)d.B * d.P;
+    const int G = gridDim.x * 4;
+    int* sd = &S.d[0][0];
+    long long pa = 0, pb = 0, pc = 0, pn = 0, psw = 0, pac = 0;
+    for (int t = blockIdx.x * 4 + wv; t < n_in; t += G) {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));                                     // keeps the lane arithmetic inside the loop (no hoist + spill)
+        const long long t_a = PROF ? wall_clock64() : 0;
+        const int tile = __builtin_amdgcn_readfirstlane(list_in[t]);
+        const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
+        const int tyi = tr / tl.pt_x, txi = tr % tl.pt_x;
+        const size_t base = (size_t)b * d.P;
+        const int lx = lane & 31, r0 = lane >> 5;
+        const int x = txi * PT_W + lx;
+        int e0[PX], sk0[PX], d0[PX], r0v[PX][8], pp[PX];
+        bool inb[PX];
+        // all loads of the visit are issued unconditionally from clamped addresses, then masked
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int y = tyi * PT_H + r0 + 2 * j;
+            inb[j] = x < d.W && y < d.H;
+            pp[j] = y * d.W + x;
+            const int pc = min(y, d.H - 1) * d.W + min(x, d.W - 1);
+            e0[j] = ex[base + pc];
+            sk0[j] = snk[base + pc];
+#pragma unroll
+            for (int dir = 0; dir < 8; ++dir) r0v[j][dir] = rc[(size_t)dir * BP + base + pc];
+        }
+        int hv[HALO_IT];
+#pragma unroll
+        for (int k = 0; k < HALO_IT; ++k) {
+            const int i = min(lane + k * 64, N_HALO - 1);
+            const int gy = tyi * PT_H + i / (PT_W + 2) - 1, gx = txi * PT_W + i % (PT_W + 2) - 1;
+            hv[k] = dist[base + (size_t)min(max(gy, 0), d.H - 1) * d.W + min(max(gx, 0), d.W - 1)];
+        }
+        if (lane == 0) flag_in[tile] = 0;                                  // consumed
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int slot = lane + 64 * j;
+            if (!inb[j]) { e0[j] = 0; sk0[j] = 0; }
+            S.ex[slot] = e0[j];
+            S.sk[slot] = sk0[j];
+#pragma unroll
+            for (int dir = 0; dir < 8; ++dir) {
+                if (!inb[j]) r0v[j][dir] = 0;
+                S.rc[dir][slot] = r0v[j][dir];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < HALO_IT; ++k) {
+            const int i = lane + k * 64;
+            const int gy = tyi * PT_H + i / (PT_W + 2) - 1, gx = txi * PT_W + i % (PT_W + 2) - 1;
+            if (i < N_HALO) sd[i] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? hv[k] : DINF;
+        }
+        mf_wave_sync();
+#pragma unroll
+        for (int j = 0; j < PX; ++j) d0[j] = S.d[r0 + 2 * j + 1][lx + 1];
+        const long long t_b = PROF ? wall_clock64() : 0;
+        int n_sw = 0, n_ac = 0, nbm = 0;                                   // nbm bit (dy + 1) * 3 + (dx + 1): neighbour tile received excess
+        for (int it = 0; it < inner; ++it) {
+            // ---- compact the active pixels of the tile (slot order)
+            int n_act = 0;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const int slot = lane + 64 * j;
+                const bool a = inb[j] && S.ex[slot] > 0 && S.d[r0 + 2 * j + 1][lx + 1] < d.P;
+                const unsigned long long m = __ballot(a);
+                if (a) S.act[n_act + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)slot;
+                n_act += __popcll(m);
+            }
+            mf_wave_sync();
+            if (n_act == 0) break;
+            if (PROF) { ++n_sw; n_ac += n_act; }
+            // ---- one active pixel per lane
+            for (int k0 = 0; k0 < n_act; k0 += 64) {
+                const int k = k0 + lane;
+                if (k < n_act) {
+                    const int slot = S.act[k], ly = slot >> 5, plx = slot & 31;
+                    const int e = __hip_atomic_load(&S.ex[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int dp = S.d[ly + 1][plx + 1];
+                    const int sk = S.sk[slot];
+                    int r[8], hq[8];
+#pragma unroll
+                    for (int dir = 0; dir < 8; ++dir) {
+                        r[dir] = __hip_atomic_load(&S.rc[dir][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        hq[dir] = S.d[ly + 1 + dir_dy(dir)][plx + 1 + dir_dx(dir)];
+                    }
+                    int hmin = sk > 0 ? 0 : DINF, best = sk > 0 ? 8 : -1, rb = 0;
+#pragma unroll
+                    for (int dir = 0; dir < 8; ++dir) {
+                        const bool ok = r[dir] > 0 && hq[dir] < hmin;
+                        hmin = ok ? hq[dir] : hmin; best = ok ? dir : best; rb = ok ? r[dir] : rb;
+                    }
+                    if (best >= 0 && dp > hmin) {
+                        if (best == 8) {
+                            const int dl = min(e, sk);
+                            S.sk[slot] = sk - dl;                          // only this lane touches the pixel's sink link
+                            atomicSub(&S.ex[slot], dl);
+                        } else {
+                            const int dl = min(e, rb);
+                            atomicSub(&S.rc[best][slot], dl);
+                            atomicSub(&S.ex[slot], dl);
+                            const int qlx = plx + dir_dx(best), qly = ly + dir_dy(best);
+                            if (qlx >= 0 && qlx < PT_W && qly >= 0 && qly < PT_H) {
+                                const int qt = qly * PT_W + qlx;
+                                atomicAdd(&S.rc[best ^ 1][qt], dl);
+                                atomicAdd(&S.ex[qt], dl);
+                            } else {                                        // across the tile edge: straight to global memory
+                                const int gy = tyi * PT_H + qly, gx = txi * PT_W + qlx;
+                                const size_t qg = base + (size_t)gy * d.W + gx;
+                                atomicAdd(&rc[(size_t)(best ^ 1) * BP + qg], dl);
+                                atomicAdd(&ex[qg], dl);
+                                // the neighbour tile is told AFTER the sweeps: its membership flag is a global load + exchange, and a
+                                // load inside the sweep loop waits for every atomic issued before it (measured: 10.8 us per sweep)
+                                const int tdy = qly < 0 ? -1 : (qly >= PT_H ? 1 : 0), tdx = qlx < 0 ? -1 : (qlx >= PT_W ? 1 : 0);
+                                nbm |= 1 << ((tdy + 1) * 3 + tdx + 1);
+                            }
+                        }
+                    } else {
+                        S.d[ly + 1][plx + 1] = (best >= 0 && hmin < DINF) ? hmin + 1 : DINF;
+                    }
+                }
+                mf_wave_sync();
+            }
+        }
+        const long long t_c = PROF ? wall_clock64() : 0;
+        int left = 0;
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            // only the border ring can receive pushes from other tiles during this launch: the interior is a plain store
+            const int slot = lane + 64 * j, ly = r0 + 2 * j, p = pp[j];
+            const bool ring = lx == 0 || lx == PT_W - 1 || ly == 0 || ly == PT_H - 1;
+            const int e1 = S.ex[slot], sk1 = S.sk[slot], d1 = S.d[ly + 1][lx + 1];
+            int r1[8];
+#pragma unroll
+            for (int dir = 0; dir < 8; ++dir) r1[dir] = S.rc[dir][slot];
+            if (!inb[j]) continue;
+            if (e1 != e0[j]) { if (ring) atomicAdd(&ex[base + p], e1 - e0[j]); else ex[base + p] = e1; }
+            int m1 = 0, chg = 0;
+#pragma unroll
+            for (int dir = 0; dir < 8; ++dir) {
+                m1 |= (r1[dir] > 0) ? (1 << dir) : 0;
+                if (r1[dir] != r0v[j][dir]) {
+                    chg = 1;
+                    const bool out = (ly == 0 && dir_dy(dir) < 0) || (ly == PT_H - 1 && dir_dy(dir) > 0) ||
+                                     (lx == 0 && dir_dx(dir) < 0) || (lx == PT_W - 1 && dir_dx(dir) > 0);   // (see k_mf_pr_list)
+                    if (out) atomicAdd(&rc[(size_t)dir * BP + base + p], r1[dir] - r0v[j][dir]);
+                    else rc[(size_t)dir * BP + base + p] = r1[dir];
+                }
+            }
+            if (chg) rmask[base + p] = (uint8_t)m1;         // (arcs that leave the tile: the relabel reads the capacities, see k_mf_dinit)
+            if (sk1 != sk0[j]) snk[base + p] = sk1;
+            if (d1 != d0[j]) dist[base + p] = d1;
+            left |= (e1 > 0 && d1 < d.P) ? 1 : 0;
+        }
+        nbm = mf_wave_or(nbm | (left ? 1 << 4 : 0));                       // bit 4: this tile still has work
+        if (lane < 9 && (nbm >> lane) & 1) {
+            const int ty = tyi + lane / 3 - 1, tx = txi + lane % 3 - 1;    // (a push never leaves the image: those arcs have no capacity)
+            if (ty >= 0 && ty < tl.pt_y && tx >= 0 && tx < tl.pt_x)
+                push_tile_l(b * tiles_per_image + ty * tl.pt_x + tx, flag_out, outl, list_out, n_out);
+        }
+        mf_wave_sync();
+        if (PROF) {      // GGC_MF_TRACE: where a visit's time goes (wall_clock64 ticks at 100 MHz), kept in registers until the wave ends
+            pa += t_b - t_a; pb += t_c - t_b; pc += wall_clock64() - t_c; pn += 1; psw += n_sw; pac += n_ac;
+        }
+    }
+    if (PROF && (threadIdx.x & 63) == 0 && pn) {                           // one set of atomics per wave, spread over 64 slots
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(prof) + (blockIdx.x & 63) * 8;
+        atomicAdd(&q[0], (unsigned long long)pa); atomicAdd(&q[1], (unsigned long long)pb); atomicAdd(&q[2], (unsigned long long)pc);
+        atomicAdd(&q[3], (unsigned long long)pn); atomicAdd(&q[4], (unsigned long long)psw); atomicAdd(&q[5], (unsigned long long)pac);
+    }
+    flush_tiles(outl, list_out, n_out);
 }
 
 // per image: number of pixels whose excess can still reach the sink; their push tiles form the round's first work list
@@ -464,18 +713,22 @@ __global__ void __launch_bounds__(256) k_mf_active(GcDims d, MfTiles tl, const i
                                                    const int32_t* __restrict__ ex, const int32_t* __restrict__ dist,
                                                    int32_t* __restrict__ active, int32_t* __restrict__ flag,
                                                    int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    __shared__ OutList outl;
+    if (threadIdx.x == 0) outl.n = 0;
+    __syncthreads();
     const int b = open_list[blockIdx.y];
     int n = 0;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.P; p += gridDim.x * blockDim.x) {
         const bool a = ex[(size_t)b * d.P + p] > 0 && dist[(size_t)b * d.P + p] < DINF;
         if (a) {
             const int y = p / d.W, x = p - y * d.W;
-            push_tile(b * tl.pt_x * tl.pt_y + (y / PT_H) * tl.pt_x + x / PT_W, flag, list, count);
+            push_tile_l(b * tl.pt_x * tl.pt_y + (y / PT_H) * tl.pt_x + x / PT_W, flag, outl, list, count);
         }
         n += a ? 1 : 0;
     }
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(&active[b], n);
+    flush_tiles(outl, list, count);
 }
 
 // closes images without active pixels and compacts the still-open ones into the next launch list
@@ -547,12 +800,17 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     int32_t *aq = nullptr, *busy = nullptr;
     if (async_relax || async_push_active > 0) {
         GGC_REQUIRE(ctx, ring_cap < (1u << 24), GGC_E_UNSUPPORTED, "batch has more max-flow tiles than a queue entry addresses");
-        ring = scratch_t<unsigned long long>(ctx, S_GC_O, ring_cap + (AQ_WORDS + n_pt + 1) / 2 + 1);
+        ring = scratch_t<unsigned long long>(ctx, S_GC_O, ring_cap + (AQ_WORDS + n_pt + 1) / 2 + 1 + 64 * 8 + 2);
         if (!ring) return GGC_E_OOM;
         aq = reinterpret_cast<int32_t*>(ring + ring_cap);
         busy = aq + AQ_WORDS;
     }
     std::vector<int32_t> host;
+    long long* prof_dev = nullptr;                                         // GGC_MF_TRACE: visit-phase clocks of k_mf_pr_wave
+    if (std::getenv("GGC_MF_TRACE") != nullptr && ring) {
+        prof_dev = reinterpret_cast<long long*>(busy + ((n_pt + 3) & ~(size_t)1));          // (the scratch block is sized for it below)
+        GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, 64 * 8 * sizeof(long long), st));
+    }
     GGC_HIP(ctx, hipMemsetAsync(n_open, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_open_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, list_cur, n_open);
     GGC_LAUNCH_CHECK(ctx);
@@ -696,9 +954,18 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             // an active pixel opens at most its own tile: empty blocks only add dispatch time to launches that are pure latency
             static const int grid_per_active = env_int("GGC_MF_GRID_PER_ACTIVE", 2);
             const int grid = (int)std::min<long long>(pr_grid, std::max<long long>(128, (long long)total_active * grid_per_active));
+            static const int pr_wgrid_cap = env_int("GGC_MF_PRW_GRID", 1024);
             static const int ppt = env_int("GGC_MF_PPT", 1);   // 2 measured 3 % slower end to end: the longer visit outweighs the tiles in flight
+            static const int pr_wave = env_int0("GGC_MF_PR_WAVE", 0);   // 1: wave-per-tile kernel (same speed; its visit-phase clocks are what GGC_MF_TRACE prints)
+            const int wgrid = (int)std::min<long long>((long long)pr_wgrid_cap * (long long)scale, std::max<long long>(32, (long long)total_active * grid_per_active / 4));
             for (int phase = 0; phase < launches; ++phase) {
-                if (ppt == 2)
+                if (pr_wave && trace)
+                    hipLaunchKernelGGL(k_mf_pr_wave<true>, dim3(wgrid), dim3(256), 0, st, d, tl, phase, sweeps, prof_dev, rc, ex, snk, dist, rmask, pr_cnt,
+                                       pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
+                else if (pr_wave)
+                    hipLaunchKernelGGL(k_mf_pr_wave<false>, dim3(wgrid), dim3(256), 0, st, d, tl, phase, sweeps, prof_dev, rc, ex, snk, dist, rmask, pr_cnt,
+                                       pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
+                else if (ppt == 2)
                     hipLaunchKernelGGL((k_mf_pr_list<2>), dim3(grid), dim3(PT_N / 2), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, rmask, pr_cnt,
                                        pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
                 else
@@ -709,6 +976,16 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             if (trace) {
                 GGC_HIP(ctx, hipStreamSynchronize(st));
                 push_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
+                if (pr_wave && prof_dev) {
+                    long long hh[64 * 8], h[6] = {0, 0, 0, 0, 0, 0};
+                    GGC_HIP(ctx, hipMemcpy(hh, prof_dev, sizeof hh, hipMemcpyDeviceToHost));
+                    GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, sizeof hh, st));
+                    for (int i = 0; i < 64; ++i) for (int k = 0; k < 6; ++k) h[k] += hh[i * 8 + k];
+                    if (h[3] > 0)
+                        std::fprintf(stderr, "    [push visits] %lld visits in %d launches (grid %d x 4 waves): per visit load+fill %.2f us, sweeps %.2f us "
+                                     "(%.1f sweeps, %.1f active pixels per sweep), write-back %.2f us\n", h[3], launches, wgrid,
+                                     0.01 * h[0] / h[3], 0.01 * h[1] / h[3], (double)h[4] / h[3], h[4] ? (double)h[5] / h[4] : 0.0, 0.01 * h[2] / h[3]);
+                }
             }
         }
     }
