@@ -110,6 +110,46 @@ __global__ void k_mf_list_all(int n_open, const int32_t* __restrict__ open_list,
     flag[tile] = 1;
 }
 
+// Start of a global relabel by TILES (the wave-per-tile relabel kernels): a wave writes the starting labels of one 32x32
+// tile (1 next to the sink, infinity elsewhere) and puts the tile on the first work list only if it holds a pixel WITHOUT a
+// sink link — a tile whose pixels all touch the sink (59 % of the bench's pixels are definite background) is final at
+// label 1 and never needs a visit.  Replaces k_mf_dinit<false> + k_mf_list_all.
+__global__ void __launch_bounds__(256) k_mf_rinit(GcDims d, MfTiles tl, const int32_t* __restrict__ open_list,
+                                                  const int32_t* __restrict__ snk, int32_t* __restrict__ dist,
+                                                  int32_t* __restrict__ list, int32_t* __restrict__ flag, int32_t* __restrict__ count) {
+    constexpr int T = MF_RT;
+    __shared__ OutList outl;
+    if (threadIdx.x == 0) outl.n = 0;
+    __syncthreads();
+    const int tiles_per_image = tl.rt_x * tl.rt_y;
+    const int tr = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tr < tiles_per_image) {
+        const int b = open_list[blockIdx.y];
+        const int ty0 = (tr / tl.rt_x) * T, tx0 = (tr % tl.rt_x) * T;
+        const int lx = lane & 31, h = lane >> 5;
+        const size_t base = (size_t)b * d.P;
+        int sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = snk[base + (size_t)min(ty0 + 16 * h + r, d.H - 1) * d.W + min(tx0 + lx, d.W - 1)];
+        bool open_px = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int y = ty0 + 16 * h + r, x = tx0 + lx;
+            if (x < d.W && y < d.H) {
+                dist[base + (size_t)y * d.W + x] = sv[r] > 0 ? 1 : DINF;
+                open_px |= sv[r] <= 0;
+            }
+        }
+        if (__any(open_px) && lane == 0) {
+            const int tile = b * tiles_per_image + tr;
+            flag[tile] = 1;                                                // (flags were cleared before the launch; one writer per tile)
+            const int i = atomicAdd(&outl.n, 1);
+            if (i < OUT_CAP) outl.buf[i] = tile; else list[atomicAdd(count, 1)] = tile;
+        }
+    }
+    flush_tiles(outl, list, count);
+}
+
 // Global relabel over a work list of 32x32 tiles.
 __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int phase, const uint8_t* __restrict__ rmask,
                                                        int32_t* __restrict__ dist, int32_t* __restrict__ counters,
@@ -842,12 +882,19 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
         int relax_launches = 0;
         {
             ProfScope prof(ctx, st, "maxflow_relabel");
-            if (relax_wave) hipLaunchKernelGGL(k_mf_dinit<false>, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
-            else hipLaunchKernelGGL(k_mf_dinit<true>, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
-            GGC_HIP(ctx, hipMemsetAsync(rl_flag[0], 0, sizeof(int32_t) * n_rt * 2, st));
             const int per_image = tl.rt_x * tl.rt_y;
-            hipLaunchKernelGGL(k_mf_list_all, dim3(cdiv((size_t)n_cur * per_image, 256)), dim3(256), 0, st, n_cur, list_cur, per_image,
-                               rl_list[0], rl_flag[0], rl_cnt);
+            GGC_HIP(ctx, hipMemsetAsync(rl_flag[0], 0, sizeof(int32_t) * n_rt * 2, st));
+            static const bool tile_init = env_int0("GGC_MF_TILE_INIT", 1) != 0;
+            if (relax_wave && tile_init) {
+                GGC_HIP(ctx, hipMemsetAsync(rl_cnt, 0, sizeof(int32_t) * 3, st));
+                hipLaunchKernelGGL(k_mf_rinit, dim3(cdiv(per_image, 4), n_cur), dim3(256), 0, st, d, tl, list_cur, snk, dist, rl_list[0], rl_flag[0],
+                                   rl_cnt);
+            } else {
+                if (relax_wave) hipLaunchKernelGGL(k_mf_dinit<false>, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
+                else hipLaunchKernelGGL(k_mf_dinit<true>, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
+                hipLaunchKernelGGL(k_mf_list_all, dim3(cdiv((size_t)n_cur * per_image, 256)), dim3(256), 0, st, n_cur, list_cur, per_image,
+                                   rl_list[0], rl_flag[0], rl_cnt);
+            }
             int phase = 0;
             if (async_relax && relax_wave) {
                 // the first launches relax every tile of the open images (bandwidth work, plain stores); the long sparse rest of
