@@ -129,7 +129,8 @@ def pmc_traffic(workload: str, batch: int):
     for rel in (PMC_SUMMARY, "profiles/r01_pmc_bench_hbm.json"):
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), rel)) as fh:
-                return int(json.load(fh)["kernels"]["k_aggregate_graph<128, 0, 32, true>"]["hbm_bytes_per_launch"]), rel
+                summary = json.load(fh)
+                return int(summary.get("kernels", summary)["k_aggregate_graph<128, 0, 32, true>"]["hbm_bytes_per_launch"]), rel
         except (OSError, KeyError, ValueError):
             continue
     return None, None

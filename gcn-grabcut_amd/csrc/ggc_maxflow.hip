@@ -832,7 +832,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     // asynchronous single-launch drivers of the sparse phases (ggc_maxflow_async.hip): ring of the larger tile count, the
     // queue words, one lock word per push tile
     static const int async_relax = env_int0("GGC_MF_ASYNC_RELAX", 1), relax_dense = env_int0("GGC_MF_RELAX_DENSE", 2);
-    static const int async_push_active = env_int0("GGC_MF_ASYNC_PUSH_ACTIVE", 20000), async_gen = env_int("GGC_MF_ASYNC_GEN", 32);
+    static const int async_push_active = env_int0("GGC_MF_ASYNC_PUSH_ACTIVE", 10000), async_gen = env_int("GGC_MF_ASYNC_GEN", 24);
     static const int async_inner = env_int("GGC_MF_ASYNC_INNER", 12), async_grid = env_int("GGC_MF_ASYNC_GRID", 128);
     static const int async_th = env_int("GGC_MF_ASYNC_TH", 8);
     const size_t ring_cap = std::max(n_rt, n_pt);

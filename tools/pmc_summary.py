@@ -12,6 +12,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)          # drop the argument list
     name = re.sub(r"^void\s+", "", name)
     return name.replace("ggc::", "").strip()

@@ -30,7 +30,7 @@ tot = sum(hist.values())
 print("time by number of kernels in flight:", {k: round(v / 1e6, 2) for k, v in sorted(hist.items())})
 byn = collections.defaultdict(lambda: [0, 0])
 for e in step:
-    n = e[2].split("(")[0][-60:]
+    n = e[2].replace("(anonymous namespace)::", "").split("(")[0][-60:]
     byn[n][0] += 1; byn[n][1] += e[1] - e[0]
 print("kernel, launches, total ms, mean us")
 for n, (c, t) in sorted(byn.items(), key=lambda kv: -kv[1][1])[:28]:
