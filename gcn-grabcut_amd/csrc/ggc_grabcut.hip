@@ -524,12 +524,12 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
         const int q = dir_nb(d, y, x, dir ^ 1);
         const int32_t c1 = q >= 0 ? nwb[(size_t)k * BP + q] : 0;
         if (warm) {   // keep the n-link flow of the previous iteration: net inflow = sum (residual - capacity)
-            const int32_t ra = rc[(size_t)dir * BP + i], rb = rc[(size_t)(dir ^ 1) * BP + i];
+            const int32_t ra = rc[rc_idx(dir, i)], rb = rc[rc_idx((dir ^ 1), i)];
             inflow += (ra - c0) + (rb - c1);
             arcs |= (ra > 0 ? 1 << dir : 0) | (rb > 0 ? 1 << (dir ^ 1) : 0);
         } else {
-            rc[(size_t)dir * BP + i] = c0;
-            rc[(size_t)(dir ^ 1) * BP + i] = c1;
+            rc[rc_idx(dir, i)] = c0;
+            rc[rc_idx((dir ^ 1), i)] = c1;
             arcs |= (c0 > 0 ? 1 << dir : 0) | (c1 > 0 ? 1 << (dir ^ 1) : 0);
         }
     }

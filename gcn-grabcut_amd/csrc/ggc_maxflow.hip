@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __res
     if (REBUILD) {
         int m = 0;
 #pragma unroll
-        for (int dir = 0; dir < 8; ++dir) m |= (rc[(size_t)dir * BP + i] > 0) ? (1 << dir) : 0;
+        for (int dir = 0; dir < 8; ++dir) m |= (rc[rc_idx(dir, i)] > 0) ? (1 << dir) : 0;
         rmask[i] = (uint8_t)m;
     }
 }
@@ -262,7 +262,8 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
 // vertical and horizontal in-register sweeps (ggc_mf_sweep.h), which carry a front across the tile in a handful of
 // sweeps where the neighbour-at-a-time iteration above needs one per pixel of the way.  32x32 tiles only.
 struct RelaxWaveLds { int d[MF_RT + 2][MF_RT + 2]; uint32_t m[MF_RT][MF_RT / 4]; };
-__global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int phase, const uint8_t* __restrict__ rmask,
+template <bool PROF>
+__global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int phase, long long* __restrict__ prof, const uint8_t* __restrict__ rmask,
                                                        const int32_t* __restrict__ rc, int32_t* __restrict__ dist, int32_t* __restrict__ counters,
                                                        const int32_t* __restrict__ list_in, int32_t* __restrict__ list_out,
                                                        int32_t* __restrict__ flag_in, int32_t* __restrict__ flag_out) {
@@ -280,10 +281,16 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
     const int G = gridDim.x * 4;
     int* sd = &S.d[0][0];
     uint8_t* sm = reinterpret_cast<uint8_t*>(&S.m[0][0]);
+    long long pa = 0, pb = 0, pc = 0, pn = 0, psw = 0;
+    // the list entry of the NEXT visit is requested one visit ahead: read at the top of its own visit it is a memory round
+    // trip in front of the tile's 50 loads (measured: load + fill 12 us of a 22 us visit)
+    int tile_nx = blockIdx.x * 4 + wv < n_in ? list_in[blockIdx.x * 4 + wv] : 0;
     for (int t = blockIdx.x * 4 + wv; t < n_in; t += G) {
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));                                     // keeps the lane arithmetic inside the loop (no hoist + spill)
-        const int tile = __builtin_amdgcn_readfirstlane(list_in[t]);
+        const long long t_a = PROF ? wall_clock64() : 0;
+        const int tile = __builtin_amdgcn_readfirstlane(tile_nx);
+        tile_nx = t + G < n_in ? list_in[t + G] : 0;
         const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
         const int tyi = tr / tl.rt_x, txi = tr % tl.rt_x;
         const int tx0 = txi * T, ty0 = tyi * T;
@@ -326,11 +333,15 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) old[r] = S.d[16 * h + r + 1][lx + 1];
         bool settled = false;
+        const long long t_b = PROF ? wall_clock64() : 0;
+        int n_sw = 0;
         for (int it = 0; it < 4 * T; ++it) {                               // a sweep pair that changes nothing: fixpoint
             const int ch = (it & 1) ? relax_sweep_h(S, inv_h, lx, h) : relax_sweep_v(S, inv_v, lx, h);
             mf_wave_sync();
+            if (PROF) ++n_sw;
             if (!__any(ch)) { settled = true; break; }
         }
+        const long long t_c = PROF ? wall_clock64() : 0;
         int nbm = settled ? 0 : 1 << 4;                                    // bit (dy + 1) * 3 + (dx + 1)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -349,6 +360,12 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
                 push_tile_l(b * tiles_per_image + ty * tl.rt_x + tx, flag_out, outl, list_out, n_out);
         }
         mf_wave_sync();
+        if (PROF) { pa += t_b - t_a; pb += t_c - t_b; pc += wall_clock64() - t_c; pn += 1; psw += n_sw; }
+    }
+    if (PROF && (threadIdx.x & 63) == 0 && pn) {                           // GGC_MF_TRACE: visit-phase clocks, one set of atomics per wave
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(prof) + (64 + (blockIdx.x & 63)) * 8;
+        atomicAdd(&q[0], (unsigned long long)pa); atomicAdd(&q[1], (unsigned long long)pb); atomicAdd(&q[2], (unsigned long long)pc);
+        atomicAdd(&q[3], (unsigned long long)pn); atomicAdd(&q[4], (unsigned long long)psw);
     }
     flush_tiles(outl, list_out, n_out);
 }
@@ -394,7 +411,7 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
             R.e[j] = in ? ex[base + p] : 0;
             R.sk[j] = in ? snk[base + p] : 0;
 #pragma unroll
-            for (int dir = 0; dir < 8; ++dir) R.r[j][dir] = in ? rc[(size_t)dir * BP + base + p] : 0;
+            for (int dir = 0; dir < 8; ++dir) R.r[j][dir] = in ? rc[rc_idx(dir, base + p)] : 0;
         }
 #pragma unroll
         for (int k = 0; k < HALO_IT; ++k) {
@@ -486,7 +503,7 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
                             } else {                                        // across the tile edge: straight to global memory
                                 const int q = pp[j] + by * d.W + bx;
                                 const int y = tyi * PT_H + ly;
-                                atomicAdd(&rc[(size_t)(best ^ 1) * BP + base + q], dl);
+                                atomicAdd(&rc[rc_idx((best ^ 1), base + q)], dl);
                                 atomicAdd(&ex[base + q], dl);
                                 // (the neighbour tile is told after the sweeps, see k_mf_pr_wave)
                                 const int tdy = qly < 0 ? -1 : (qly >= PT_H ? 1 : 0), tdx = qlx < 0 ? -1 : (qlx >= PT_W ? 1 : 0);
@@ -523,8 +540,8 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
                     // are what bounds the dense rounds)
                     const bool out = (ly == 0 && dir_dy(dir) < 0) || (ly == PT_H - 1 && dir_dy(dir) > 0) ||
                                      (lx == 0 && dir_dx(dir) < 0) || (lx == PT_W - 1 && dir_dx(dir) > 0);
-                    if (out) atomicAdd(&rc[(size_t)dir * BP + base + p], r1 - r0[j][dir]);
-                    else rc[(size_t)dir * BP + base + p] = r1;
+                    if (out) atomicAdd(&rc[rc_idx(dir, base + p)], r1 - r0[j][dir]);
+                    else rc[rc_idx(dir, base + p)] = r1;
                 }
             }
             if (chg) rmask[base + p] = (uint8_t)m1;     // (arcs that leave the tile: the relabel reads the capacities, see k_mf_dinit)
@@ -578,11 +595,13 @@ __global__ void __launch_bounds__(256) k_mf_pr_wave(GcDims d, MfTiles tl, int ph
     const int G = gridDim.x * 4;
     int* sd = &S.d[0][0];
     long long pa = 0, pb = 0, pc = 0, pn = 0, psw = 0, pac = 0;
+    int tile_nx = blockIdx.x * 4 + wv < n_in ? list_in[blockIdx.x * 4 + wv] : 0;   // (list entry one visit ahead, see k_mf_relax_wave)
     for (int t = blockIdx.x * 4 + wv; t < n_in; t += G) {
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));                                     // keeps the lane arithmetic inside the loop (no hoist + spill)
         const long long t_a = PROF ? wall_clock64() : 0;
-        const int tile = __builtin_amdgcn_readfirstlane(list_in[t]);
+        const int tile = __builtin_amdgcn_readfirstlane(tile_nx);
+        tile_nx = t + G < n_in ? list_in[t + G] : 0;
         const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
         const int tyi = tr / tl.pt_x, txi = tr % tl.pt_x;
         const size_t base = (size_t)b * d.P;
@@ -600,7 +619,7 @@ __global__ void __launch_bounds__(256) k_mf_pr_wave(GcDims d, MfTiles tl, int ph
             e0[j] = ex[base + pc];
             sk0[j] = snk[base + pc];
 #pragma unroll
-            for (int dir = 0; dir < 8; ++dir) r0v[j][dir] = rc[(size_t)dir * BP + base + pc];
+            for (int dir = 0; dir < 8; ++dir) r0v[j][dir] = rc[rc_idx(dir, base + pc)];
         }
         int hv[HALO_IT];
 #pragma unroll
@@ -684,7 +703,7 @@ __global__ void __launch_bounds__(256) k_mf_pr_wave(GcDims d, MfTiles tl, int ph
                             } else {                                        // across the tile edge: straight to global memory
                                 const int gy = tyi * PT_H + qly, gx = txi * PT_W + qlx;
                                 const size_t qg = base + (size_t)gy * d.W + gx;
-                                atomicAdd(&rc[(size_t)(best ^ 1) * BP + qg], dl);
+                                atomicAdd(&rc[rc_idx((best ^ 1), qg)], dl);
                                 atomicAdd(&ex[qg], dl);
                                 // the neighbour tile is told AFTER the sweeps: its membership flag is a global load + exchange, and a
                                 // load inside the sweep loop waits for every atomic issued before it (measured: 10.8 us per sweep)
@@ -720,8 +739,8 @@ __global__ void __launch_bounds__(256) k_mf_pr_wave(GcDims d, MfTiles tl, int ph
                     chg = 1;
                     const bool out = (ly == 0 && dir_dy(dir) < 0) || (ly == PT_H - 1 && dir_dy(dir) > 0) ||
                                      (lx == 0 && dir_dx(dir) < 0) || (lx == PT_W - 1 && dir_dx(dir) > 0);   // (see k_mf_pr_list)
-                    if (out) atomicAdd(&rc[(size_t)dir * BP + base + p], r1[dir] - r0v[j][dir]);
-                    else rc[(size_t)dir * BP + base + p] = r1[dir];
+                    if (out) atomicAdd(&rc[rc_idx(dir, base + p)], r1[dir] - r0v[j][dir]);
+                    else rc[rc_idx(dir, base + p)] = r1[dir];
                 }
             }
             if (chg) rmask[base + p] = (uint8_t)m1;         // (arcs that leave the tile: the relabel reads the capacities, see k_mf_dinit)
@@ -840,7 +859,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     int32_t *aq = nullptr, *busy = nullptr;
     if (async_relax || async_push_active > 0) {
         GGC_REQUIRE(ctx, ring_cap < (1u << 24), GGC_E_UNSUPPORTED, "batch has more max-flow tiles than a queue entry addresses");
-        ring = scratch_t<unsigned long long>(ctx, S_GC_O, ring_cap + (AQ_WORDS + n_pt + 1) / 2 + 1 + 64 * 8 + 2);
+        ring = scratch_t<unsigned long long>(ctx, S_GC_O, ring_cap + (AQ_WORDS + n_pt + 1) / 2 + 1 + 128 * 8 + 2);
         if (!ring) return GGC_E_OOM;
         aq = reinterpret_cast<int32_t*>(ring + ring_cap);
         busy = aq + AQ_WORDS;
@@ -849,7 +868,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     long long* prof_dev = nullptr;                                         // GGC_MF_TRACE: visit-phase clocks of k_mf_pr_wave
     if (std::getenv("GGC_MF_TRACE") != nullptr && ring) {
         prof_dev = reinterpret_cast<long long*>(busy + ((n_pt + 3) & ~(size_t)1));          // (the scratch block is sized for it below)
-        GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, 64 * 8 * sizeof(long long), st));
+        GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, 128 * 8 * sizeof(long long), st));
     }
     GGC_HIP(ctx, hipMemsetAsync(n_open, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_open_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, list_cur, n_open);
@@ -900,7 +919,9 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
                 // the first launches relax every tile of the open images (bandwidth work, plain stores); the long sparse rest of
                 // the front runs asynchronously inside one launch that ends at the fixpoint: nothing to read back
                 for (; phase < relax_dense; ++phase)
-                    hipLaunchKernelGGL(k_mf_relax_wave, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, rmask, rc, dist, rl_cnt,
+                    if (trace && prof_dev) hipLaunchKernelGGL(k_mf_relax_wave<true>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, rc, dist, rl_cnt,
+                                       rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
+                    else hipLaunchKernelGGL(k_mf_relax_wave<false>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, rc, dist, rl_cnt,
                                        rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
                 const int grid = (int)std::min<size_t>(async_grid * scale, std::max<size_t>(16, cdiv((size_t)n_cur * tl.rt_x * tl.rt_y, 16)));
                 if ((rcode = maxflow_relax_async(ctx, st, d, tl, rmask, rc, dist, rl_cnt + phase % 3, rl_list[phase & 1], rl_flag[phase & 1], ring, aq,
@@ -911,7 +932,9 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             for (int guard = 0; guard < 100000; ++guard) {
                 for (int rep = 0; rep < relax_rep; ++rep, ++phase) {
                     if (relax_wave)
-                        hipLaunchKernelGGL(k_mf_relax_wave, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, rmask, rc, dist, rl_cnt,
+                        if (trace && prof_dev) hipLaunchKernelGGL(k_mf_relax_wave<true>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, rc, dist, rl_cnt,
+                                       rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
+                    else hipLaunchKernelGGL(k_mf_relax_wave<false>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, rc, dist, rl_cnt,
                                            rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
                     else
                         hipLaunchKernelGGL(k_mf_relax_list, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
@@ -932,6 +955,16 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
         GGC_LAUNCH_CHECK(ctx);
         if ((rcode = read_i32(ctx, st, n_open, 8, host))) return rcode;
         const int n_next = host[0], total_active = host[7];
+        if (trace && prof_dev) {   // visit-phase clocks of the dense relabel launches of this round
+            long long hh[64 * 8], h[5] = {0, 0, 0, 0, 0};
+            GGC_HIP(ctx, hipStreamSynchronize(st));
+            GGC_HIP(ctx, hipMemcpy(hh, prof_dev + 64 * 8, sizeof hh, hipMemcpyDeviceToHost));
+            GGC_HIP(ctx, hipMemsetAsync(prof_dev + 64 * 8, 0, sizeof hh, st));
+            for (int i = 0; i < 64; ++i) for (int k = 0; k < 5; ++k) h[k] += hh[i * 8 + k];
+            if (h[3] > 0)
+                std::fprintf(stderr, "    [relabel visits] %lld dense visits: per visit load+fill %.2f us, sweeps %.2f us (%.1f sweeps), write-back %.2f us\n",
+                             h[3], 0.01 * h[0] / h[3], 0.01 * h[1] / h[3], (double)h[4] / h[3], 0.01 * h[2] / h[3]);
+        }
         if (trace) {   // diagnostics: active pixels / open images per round
             std::vector<int32_t> act;
             if ((rcode = read_i32(ctx, st, active, B, act))) return rcode;

@@ -233,7 +233,7 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
         e0[j] = ldg(ex + base + pc);
         sk0[j] = ldg(snk + base + pc);
 #pragma unroll
-        for (int dir = 0; dir < 8; ++dir) r0v[j][dir] = ldg(rc + (size_t)dir * BP + base + pc);
+        for (int dir = 0; dir < 8; ++dir) r0v[j][dir] = ldg(rc + rc_idx(dir, base + pc));
     }
     int* sd = &S.d[0][0];
     int hv[HALO_IT];
@@ -324,7 +324,7 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
                             } else {                                    // across the tile edge: straight to memory
                                 const int gy = tyi * TH + qly, gx = txi * 32 + qlx;
                                 const size_t qg = base + (size_t)gy * d.W + gx;
-                                atomicAdd(&rc[(size_t)(best ^ 1) * BP + qg], dl);
+                                atomicAdd(&rc[rc_idx((best ^ 1), qg)], dl);
                                 atomicAdd(&ex[qg], dl);
                                 const int tdy = qly < 0 ? -1 : (qly >= TH ? 1 : 0), tdx = qlx < 0 ? -1 : (qlx >= 32 ? 1 : 0);
                                 nbm |= 1 << ((tdy + 1) * 3 + tdx + 1);
@@ -360,7 +360,7 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
 #pragma unroll
         for (int dir = 0; dir < 8; ++dir) {
             m1 |= (r1[dir] > 0) ? (1 << dir) : 0;
-            if (r1[dir] != r0v[j][dir]) { chg = 1; atomicAdd(&rc[(size_t)dir * BP + p], r1[dir] - r0v[j][dir]); }
+            if (r1[dir] != r0v[j][dir]) { chg = 1; atomicAdd(&rc[rc_idx(dir, p)], r1[dir] - r0v[j][dir]); }
         }
         if (chg) {
             // read by the next relabel only, but a tile can be visited from several XCDs within this launch: two plain stores to

@@ -175,12 +175,12 @@ __device__ void relax_visit(const GcDims& d, const MfTiles& tl, int tile, size_t
             const int r = (q >> 1) * 8 + ((q & 1) ? 7 : 0);
             const size_t i = base + (size_t)min(ty0 + 16 * h + r, d.H - 1) * d.W + cx;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) fr[q][t] = ldg(rc + (size_t)((q & 1) ? 3 + 2 * t : 2 + 2 * t) * BP + i);   // 3,5,7 | 2,4,6
+            for (int t = 0; t < 3; ++t) fr[q][t] = ldg(rc + rc_idx(((q & 1) ? 3 + 2 * t : 2 + 2 * t), i));   // 3,5,7 | 2,4,6
         }
         const size_t i = base + (size_t)min(ty0 + lx, d.H - 1) * d.W + min(tx0 + (h ? 31 : 0), d.W - 1);   // H-sweep row lx
-        fc[0] = ldg(rc + (size_t)(h ? 1 : 0) * BP + i);
-        fc[1] = ldg(rc + (size_t)(h ? 5 : 4) * BP + i);
-        fc[2] = ldg(rc + (size_t)(h ? 6 : 7) * BP + i);
+        fc[0] = ldg(rc + rc_idx((h ? 1 : 0), i));
+        fc[1] = ldg(rc + rc_idx((h ? 5 : 4), i));
+        fc[2] = ldg(rc + rc_idx((h ? 6 : 7), i));
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -304,7 +304,7 @@ __device__ void push_visit(const GcDims& d, const MfTiles& tl, int tile, int inn
         e0[j] = ldg(ex + base + pc);
         sk0[j] = snk[base + pc];
 #pragma unroll
-        for (int dir = 0; dir < 8; ++dir) r0v[j][dir] = ldg(rc + (size_t)dir * BP + base + pc);
+        for (int dir = 0; dir < 8; ++dir) r0v[j][dir] = ldg(rc + rc_idx(dir, base + pc));
     }
     int* sd = &S.d[0][0];
     int hv[(PT_HALO + 63) / 64];
@@ -388,7 +388,7 @@ __device__ void push_visit(const GcDims& d, const MfTiles& tl, int tile, int inn
                         } else {                                        // across the tile edge: straight to global memory
                             const int gy = tyi * PT_H + ly + by, gx = txi * PT_W + plx + bx;
                             const size_t q = base + (size_t)gy * d.W + gx;
-                            atomicAdd(&rc[(size_t)(best ^ 1) * BP + q], dl);
+                            atomicAdd(&rc[rc_idx((best ^ 1), q)], dl);
                             atomicAdd(&ex[q], dl);
                             flag_tile(bm, (gy / PT_H) * tl.pt_x + gx / PT_W);
                         }
@@ -419,8 +419,8 @@ __device__ void push_visit(const GcDims& d, const MfTiles& tl, int tile, int inn
             m1 |= (r1[dir] > 0) ? (1 << dir) : 0;
             if (r1[dir] != r0v[j][dir]) {
                 chg = 1;
-                if (ring) atomicAdd(&rc[(size_t)dir * BP + base + p], r1[dir] - r0v[j][dir]);
-                else rc[(size_t)dir * BP + base + p] = r1[dir];
+                if (ring) atomicAdd(&rc[rc_idx(dir, base + p)], r1[dir] - r0v[j][dir]);
+                else rc[rc_idx(dir, base + p)] = r1[dir];
             }
         }
         if (chg) rmask[base + p] = (uint8_t)m1;             // (arcs that leave the tile: see relax_visit)

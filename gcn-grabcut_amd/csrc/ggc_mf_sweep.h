@@ -49,12 +49,12 @@ struct MfBorderArcs {
             const int r = (q >> 1) * 8 + ((q & 1) ? 7 : 0);
             const size_t i = base + (size_t)min(ty0 + 16 * h + r, d.H - 1) * d.W + cx;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) fr[q][t] = rc[(size_t)((q & 1) ? 3 + 2 * t : 2 + 2 * t) * BP + i];   // 3,5,7 | 2,4,6
+            for (int t = 0; t < 3; ++t) fr[q][t] = rc[rc_idx(((q & 1) ? 3 + 2 * t : 2 + 2 * t), i)];   // 3,5,7 | 2,4,6
         }
         const size_t i = base + (size_t)min(ty0 + lx, d.H - 1) * d.W + min(tx0 + (h ? 31 : 0), d.W - 1);   // H-sweep row lx
-        fc[0] = rc[(size_t)(h ? 1 : 0) * BP + i];
-        fc[1] = rc[(size_t)(h ? 5 : 4) * BP + i];
-        fc[2] = rc[(size_t)(h ? 6 : 7) * BP + i];
+        fc[0] = rc[rc_idx((h ? 1 : 0), i)];
+        fc[1] = rc[rc_idx((h ? 5 : 4), i)];
+        fc[2] = rc[rc_idx((h ? 6 : 7), i)];
     }
     // inverted mask of row r (0..15) of the lane's segment
     __device__ __forceinline__ uint32_t row(uint32_t m, int r) const {
