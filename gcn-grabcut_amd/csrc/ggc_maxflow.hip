@@ -1017,7 +1017,9 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             if (round > 0 && total_active <= async_push_active) {
                 // sparse round: one asynchronous launch chases the excess from tile to tile (chains of at most async_gen hops)
                 const int waves = (int)std::min<long long>(4ll * async_grid * (long long)scale, std::max<long long>(64, total_active / 4));
-                if ((rcode = maxflow_push_async(ctx, st, d, tl, async_th, async_inner, async_gen, rc, ex, snk, dist, rmask, pr_cnt, pt_list[0], (int)n_pt,
+                static const int gen_tail = env_int("GGC_MF_ASYNC_GEN_TAIL", 24), gen_tail_active = env_int("GGC_MF_ASYNC_GEN_TAIL_ACTIVE", 1000);
+                const int gen_now = total_active <= gen_tail_active ? gen_tail : async_gen;
+                if ((rcode = maxflow_push_async(ctx, st, d, tl, async_th, async_inner, gen_now, rc, ex, snk, dist, rmask, pr_cnt, pt_list[0], (int)n_pt,
                                                 busy, ring, aq, waves, err_flag)))
                     return rcode;
                 if (trace) {
