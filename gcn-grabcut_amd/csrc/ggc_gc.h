@@ -51,7 +51,7 @@ int maxflow_relax_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfT
 // visit.  list: the active scan's 32x8 push tiles (n_list_max = their number in the batch); state: one word per tile.
 int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, int th, int inner, int gen_max, int32_t* rc,
                        int32_t* ex, int32_t* snk, int32_t* dist, uint8_t* rmask, const int32_t* count, const int32_t* list, int n_list_max, int32_t* state,
-                       unsigned long long* ring, int32_t* q, int waves, int32_t* err_flag);
+                       unsigned long long* ring, int32_t* q, int waves, int32_t* err_flag, long long* prof = nullptr);
 
 // One workgroup per image runs the whole max-flow (every round of global relabel + push sweeps) in a single launch.
 // Returns GGC_E_UNSUPPORTED without touching anything when the image has more tiles than the kernel's LDS bitmap holds.

@@ -1020,11 +1020,25 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
                 static const int gen_tail = env_int("GGC_MF_ASYNC_GEN_TAIL", 24), gen_tail_active = env_int("GGC_MF_ASYNC_GEN_TAIL_ACTIVE", 1000);
                 const int gen_now = total_active <= gen_tail_active ? gen_tail : async_gen;
                 if ((rcode = maxflow_push_async(ctx, st, d, tl, async_th, async_inner, gen_now, rc, ex, snk, dist, rmask, pr_cnt, pt_list[0], (int)n_pt,
-                                                busy, ring, aq, waves, err_flag)))
+                                                busy, ring, aq, waves, err_flag, trace ? prof_dev : nullptr)))
                     return rcode;
                 if (trace) {
                     GGC_HIP(ctx, hipStreamSynchronize(st));
                     push_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
+                    if (prof_dev) {
+                        long long hh[128 * 8], h[7] = {0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+                        GGC_HIP(ctx, hipMemcpy(hh, prof_dev, sizeof hh, hipMemcpyDeviceToHost));
+                        GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, sizeof hh, st));
+                        for (int i = 0; i < 64; ++i) for (int k = 0; k < 7; ++k) h[k] += hh[i * 8 + k];
+                        for (int i = 0; i < 64; ++i) for (int k = 0; k < 3; ++k) g[k] += hh[(64 + i) * 8 + k];
+                        if (h[3] > 0)
+                            std::fprintf(stderr, "    [async visit] load+fill %.2f us, sweeps %.2f us (%.1f sweeps), write-back+drain %.2f us\n", 0.01 * g[0] / h[3],
+                                         0.01 * g[1] / h[3], (double)g[2] / h[3], 0.01 * (h[1] - g[0] - g[1]) / h[3]);
+                        if (h[6] > 0)
+                            std::fprintf(stderr, "    [async push] %d waves alive %.1f us on average; %lld visits (%lld followed): per visit wait+lock %.2f us, "
+                                         "visit %.2f us, hand-over %.2f us\n", waves, 0.01 * h[5] / h[6], h[3], h[4], h[3] ? 0.01 * h[0] / h[3] : 0.0,
+                                         h[3] ? 0.01 * h[1] / h[3] : 0.0, h[3] ? 0.01 * h[2] / h[3] : 0.0);
+                    }
                 }
                 continue;
             }

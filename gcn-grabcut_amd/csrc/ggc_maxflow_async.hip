@@ -220,8 +220,10 @@ struct PushTileLds {
 template <int TH>
 __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, size_t base, size_t BP,
                                int32_t* __restrict__ rc, int32_t* __restrict__ ex, int32_t* __restrict__ snk,
-                               int32_t* __restrict__ dist, uint8_t* __restrict__ rmask, PushTileLds<TH>& S, int lane) {
+                               int32_t* __restrict__ dist, uint8_t* __restrict__ rmask, PushTileLds<TH>& S, int lane,
+                               bool prof, long long (&pv)[4]) {
     constexpr int NPX = TH / 2, HALO = (TH + 2) * 34, HALO_IT = (HALO + 63) / 64;
+    const long long tv0 = prof ? wall_clock64() : 0;
     const int lx = lane & 31, r0 = lane >> 5;
     const int x = txi * 32 + lx;
     int e0[NPX], sk0[NPX], r0v[NPX][8];
@@ -269,20 +271,27 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
     }
     mf_wave_sync();
     int nbm = 0;
+    const long long tv1 = prof ? wall_clock64() : 0;
+    int n_sw = 0;
     for (int it = 0; it < inner; ++it) {
         // ---- bitmask -> list (row-major), mask cleared
-        const uint32_t w = lane < TH ? S.mask[lane] : 0u;
-        const int c = __popc(w);
-        int incl = c;
+        // every lane reads all TH row words (broadcast reads) and forms the row offsets itself: no cross-lane step (a prefix
+        // scan by __shfl_up is five dependent LDS-crossbar round trips, a third of a sparse sweep)
+        uint32_t w = 0u;
+        int off = 0, n_act = 0;
 #pragma unroll
-        for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        const int n_act = __shfl(incl, 31, 64);
-        if (n_act == 0) break;
-        if (lane < TH) S.mask[lane] = 0u;
-        {
-            uint32_t ww = w; int off = incl - c;
-            while (ww) { const int bit = __ffs(ww) - 1; S.list[off++] = (unsigned short)(lane * 32 + bit); ww &= ww - 1; }
+        for (int r = 0; r < TH; ++r) {
+            const uint32_t wr = S.mask[r];
+            const int cr = __popc(wr);
+            w = r == lane ? wr : w;
+            off += r < lane ? cr : 0;
+            n_act += cr;
         }
+        if (n_act == 0) break;
+        ++n_sw;
+        mf_wave_sync();                                                    // every lane has read the words before they are cleared
+        if (lane < TH) S.mask[lane] = 0u;
+        while (w) { const int bit = __ffs(w) - 1; S.list[off++] = (unsigned short)(lane * 32 + bit); w &= w - 1; }
         mf_wave_sync();
         // ---- one active pixel per lane
         for (int k0 = 0; k0 < n_act; k0 += 64) {
@@ -341,6 +350,8 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
             mf_wave_sync();
         }
     }
+    const long long tv2 = prof ? wall_clock64() : 0;
+    if (prof) { pv[0] += tv1 - tv0; pv[1] += tv2 - tv1; pv[2] += n_sw; }
     int left = 0;
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
@@ -392,20 +403,26 @@ template <int TH>
 __global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt_y, int inner, int gen_max, int follow, int32_t* __restrict__ rc,
                                                       int32_t* __restrict__ ex, int32_t* __restrict__ snk, int32_t* __restrict__ dist,
                                                       uint8_t* __restrict__ rmask, int32_t* __restrict__ st, unsigned long long* __restrict__ ring,
-                                                      int32_t* __restrict__ q, int cap, int32_t* __restrict__ err_flag) {
+                                                      int32_t* __restrict__ q, int cap, int32_t* __restrict__ err_flag,
+                                                      long long* __restrict__ prof) {
     __shared__ PushTileLds<TH> S;
     const int tiles_per_image = bt_x * bt_y;
     const size_t BP = (size_t)d.B * d.P;
     const int budget = ldg(&q[AQ_BUDGET]);
     int tile = -1, gen = 0;
+    // GGC_MF_TRACE (prof != null): where a wave's time goes — waiting for a queue entry, the visit, the hand-over — in
+    // wall_clock64 ticks, kept in registers and added up once when the wave leaves
+    long long p_wait = 0, p_visit = 0, p_hand = 0, p_n = 0, p_follow = 0, pv[4] = {0, 0, 0, 0};
+    const long long t_start = prof ? wall_clock64() : 0;
     for (;;) {
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));
+        const long long t_0 = prof ? wall_clock64() : 0;
         if (tile < 0) {
             const int payload = aq_pop(ring, q, cap, lane, err_flag);
-            if (payload < 0) break;
+            if (payload < 0) { if (prof) p_wait += wall_clock64() - t_0; break; }
             tile = payload & 0xffffff; gen = payload >> 24;
-        }
+        } else if (prof) ++p_follow;
         // A tile that is queued (or followed into) is never busy: it is only queued from the idle state, and its holder
         // re-queues it after letting go.  Busy from here on; excess that arrives meanwhile sets `queued` again.
         int over = 0;
@@ -415,10 +432,12 @@ __global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt
             if (over) atomicExch(&q[AQ_DONE], 1);
         }
         drain();                                                           // ... before the tile is loaded
+        const long long t_1 = prof ? wall_clock64() : 0;
         const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
         const int tyi = tr / bt_x, txi = tr % bt_x;
-        const int nbm = push_tile_visit<TH>(d, tyi, txi, inner, (size_t)b * d.P, BP, rc, ex, snk, dist, rmask, S, lane);
+        const int nbm = push_tile_visit<TH>(d, tyi, txi, inner, (size_t)b * d.P, BP, rc, ex, snk, dist, rmask, S, lane, prof != nullptr, pv);
         drain();                                                           // the write-back is at memory
+        const long long t_2 = prof ? wall_clock64() : 0;
         const bool left = (nbm >> 4) & 1;
         int nb = -1;
         bool cand = false;
@@ -446,6 +465,15 @@ __global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt
         if (next < 0 && lane == 0) aq_finish(q);
         tile = next; gen = gen + 1;
         mf_wave_sync();
+        if (prof) { p_wait += t_1 - t_0; p_visit += t_2 - t_1; p_hand += wall_clock64() - t_2; ++p_n; }
+    }
+    if (prof && (threadIdx.x & 63) == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(prof) + (blockIdx.x & 63) * 8;
+        atomicAdd(&o[0], (unsigned long long)p_wait); atomicAdd(&o[1], (unsigned long long)p_visit); atomicAdd(&o[2], (unsigned long long)p_hand);
+        atomicAdd(&o[3], (unsigned long long)p_n); atomicAdd(&o[4], (unsigned long long)p_follow);
+        atomicAdd(&o[5], (unsigned long long)(wall_clock64() - t_start)); atomicAdd(&o[6], 1ull);
+        unsigned long long* o2 = o + 64 * 8;                               // second table: inside the visit
+        atomicAdd(&o2[0], (unsigned long long)pv[0]); atomicAdd(&o2[1], (unsigned long long)pv[1]); atomicAdd(&o2[2], (unsigned long long)pv[2]);
     }
 }
 
@@ -479,7 +507,7 @@ int maxflow_relax_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfT
 
 int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, int th, int inner, int gen_max, int32_t* rc,
                        int32_t* ex, int32_t* snk, int32_t* dist, uint8_t* rmask, const int32_t* count, const int32_t* list, int n_list_max, int32_t* state,
-                       unsigned long long* ring, int32_t* q, int waves, int32_t* err_flag) {
+                       unsigned long long* ring, int32_t* q, int waves, int32_t* err_flag, long long* prof) {
     th = th >= 32 ? 32 : (th >= 16 ? 16 : 8);
     const int bt_x = tl.pt_x, bt_y = cdiv(d.H, th), cap = bt_x * bt_y * d.B;
     gen_max = std::min(gen_max, 127);
@@ -491,13 +519,13 @@ int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTi
                        gen_max);
     if (th == 32)
         hipLaunchKernelGGL(k_mf_push_async<32>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, rmask, state, ring, q, cap,
-                           err_flag);
+                           err_flag, prof);
     else if (th == 8)
         hipLaunchKernelGGL(k_mf_push_async<8>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, rmask, state, ring, q, cap,
-                           err_flag);
+                           err_flag, prof);
     else
         hipLaunchKernelGGL(k_mf_push_async<16>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, rmask, state, ring, q, cap,
-                           err_flag);
+                           err_flag, prof);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
 }
