@@ -44,13 +44,13 @@ struct MfTiles { int rt_x, rt_y, pt_x, pt_y; };    // tiles per image
 constexpr int AQ_HEAD = 0, AQ_TAIL = 32, AQ_PENDING = 64, AQ_DONE = 96, AQ_BUDGET = 97, AQ_VISITS = 128, AQ_WORDS = 160;
 // queue <- list[0 .. *count) (device-side count; the tiles' membership flags in `flag` are set), then ONE launch that ends
 // at the relabel's fixpoint.  ring: cap 64-bit slots, cap = number of relabel tiles of the batch.
-int maxflow_relax_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, const uint8_t* rmask, const int32_t* rc, int32_t* dist,
+int maxflow_relax_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, uint8_t* rmask, int32_t* dirty, const int32_t* rc, int32_t* dist,
                         const int32_t* count, const int32_t* list, int32_t* flag, unsigned long long* ring, int32_t* q, int cap,
                         int grid, int32_t* err_flag);
 // the same for one push phase on 32 x th tiles (th = 16 | 32): chains of at most gen_max tile hops, at most `inner` sweeps per
 // visit.  list: the active scan's 32x8 push tiles (n_list_max = their number in the batch); state: one word per tile.
 int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, int th, int inner, int gen_max, int32_t* rc,
-                       int32_t* ex, int32_t* snk, int32_t* dist, uint8_t* rmask, const int32_t* count, const int32_t* list, int n_list_max, int32_t* state,
+                       int32_t* ex, int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* dirty, const int32_t* count, const int32_t* list, int n_list_max, int32_t* state,
                        unsigned long long* ring, int32_t* q, int waves, int32_t* err_flag, long long* prof = nullptr);
 
 // One workgroup per image runs the whole max-flow (every round of global relabel + push sweeps) in a single launch.

@@ -263,8 +263,8 @@ __global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int
 // sweeps where the neighbour-at-a-time iteration above needs one per pixel of the way.  32x32 tiles only.
 struct RelaxWaveLds { int d[MF_RT + 2][MF_RT + 2]; uint32_t m[MF_RT][MF_RT / 4]; };
 template <bool PROF>
-__global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int phase, long long* __restrict__ prof, const uint8_t* __restrict__ rmask,
-                                                       const int32_t* __restrict__ rc, int32_t* __restrict__ dist, int32_t* __restrict__ counters,
+__global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int phase, long long* __restrict__ prof, uint8_t* __restrict__ rmask,
+                                                       int32_t* __restrict__ dirty, const int32_t* __restrict__ rc, int32_t* __restrict__ dist, int32_t* __restrict__ counters,
                                                        const int32_t* __restrict__ list_in, int32_t* __restrict__ list_out,
                                                        int32_t* __restrict__ flag_in, int32_t* __restrict__ flag_out) {
     constexpr int T = MF_RT, N_HALO = (T + 2) * (T + 2), HALO_IT = (N_HALO + 63) / 64;
@@ -307,14 +307,16 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             mv[r] = rmask[base + (size_t)min(ty0 + 16 * h + r, d.H - 1) * d.W + min(tx0 + lx, d.W - 1)];
+        const bool dirty_t = mf_tile_dirty(dirty, tl, b, tyi, txi, lane);  // wave-uniform: a neighbour pushed into one of its push tiles
         MfBorderArcs ba;
-        ba.load(d, rc, BP, base, ty0, tx0, lx, h);
+        if (dirty_t) ba.load(d, rc, BP, base, ty0, tx0, lx, h);
         if (lane == 0) flag_in[tile] = 0;                                  // consumed
         uint32_t inv_v[4] = {0u, 0u, 0u, 0u}, inv_h[4];                    // bit set = no arc; outside the image: all blocked
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const uint32_t m = (tx0 + lx < d.W && ty0 + 16 * h + r < d.H) ? ba.row(~mv[r] & 0xffu, r) : 0xffu;
-            sm[(16 * h + r) * T + lx] = (uint8_t)m;
+            uint32_t m = ~mv[r] & 0xffu;
+            if (dirty_t) m = ba.row(m, r);
+            sm[(16 * h + r) * T + lx] = (uint8_t)((tx0 + lx < d.W && ty0 + 16 * h + r < d.H) ? m : 0xffu);
         }
 #pragma unroll
         for (int k = 0; k < HALO_IT; ++k) {
@@ -323,8 +325,11 @@ __global__ void __launch_bounds__(256) k_mf_relax_wave(GcDims d, MfTiles tl, int
             if (i < N_HALO) sd[i] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? hv[k] : DINF;
         }
         mf_wave_sync();
-        if (ty0 + lx < d.H && tx0 + (h ? 31 : 0) < d.W) sm[lx * T + (h ? 31 : 0)] = (uint8_t)ba.col(sm[lx * T + (h ? 31 : 0)], h);
-        mf_wave_sync();
+        if (dirty_t) {
+            if (ty0 + lx < d.H && tx0 + (h ? 31 : 0) < d.W) sm[lx * T + (h ? 31 : 0)] = (uint8_t)ba.col(sm[lx * T + (h ? 31 : 0)], h);
+            mf_wave_sync();
+            mf_tile_repair(d, tl, rmask, dirty, S, base, b, tyi, txi, ty0, tx0, lx, h, lane);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) inv_v[r >> 2] |= (uint32_t)sm[(16 * h + r) * T + lx] << (8 * (r & 3));
 #pragma unroll
@@ -377,7 +382,7 @@ template <int PPT>
 __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl, int phase, int inner,
                                                           int32_t* __restrict__ rc, int32_t* __restrict__ ex,
                                                           int32_t* __restrict__ snk, int32_t* __restrict__ dist, uint8_t* __restrict__ rmask,
-                                                          int32_t* __restrict__ counters, const int32_t* __restrict__ list_in,
+                                                          int32_t* __restrict__ dirty, int32_t* __restrict__ counters, const int32_t* __restrict__ list_in,
                                                           int32_t* __restrict__ list_out, int32_t* __restrict__ flag_in,
                                                           int32_t* __restrict__ flag_out) {
     constexpr int NT = PT_N / PPT;                                         // threads; pixel slot of (thread, j) = tid + j * NT
@@ -555,8 +560,11 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
         __syncthreads();
         if (tid < 9 && (s_nbm >> tid) & 1) {
             const int ty = tyi + tid / 3 - 1, tx = txi + tid % 3 - 1;
-            if (ty >= 0 && ty < tl.pt_y && tx >= 0 && tx < tl.pt_x)
-                push_tile_l(b * tiles_per_image + ty * tl.pt_x + tx, flag_out, outl, list_out, n_out);
+            if (ty >= 0 && ty < tl.pt_y && tx >= 0 && tx < tl.pt_x) {
+                const int nbt = b * tiles_per_image + ty * tl.pt_x + tx;
+                if (tid != 4) dirty[nbt] = 1;                              // its border arcs may have been re-opened (ggc_mf_sweep.h)
+                push_tile_l(nbt, flag_out, outl, list_out, n_out);
+            }
         }
     }
     flush_tiles(outl, list_out, n_out);
@@ -576,7 +584,7 @@ template <bool PROF>
 __global__ void __launch_bounds__(256) k_mf_pr_wave(GcDims d, MfTiles tl, int phase, int inner, long long* __restrict__ prof,
                                                     int32_t* __restrict__ rc, int32_t* __restrict__ ex,
                                                     int32_t* __restrict__ snk, int32_t* __restrict__ dist, uint8_t* __restrict__ rmask,
-                                                    int32_t* __restrict__ counters, const int32_t* __restrict__ list_in,
+                                                    int32_t* __restrict__ dirty, int32_t* __restrict__ counters, const int32_t* __restrict__ list_in,
                                                     int32_t* __restrict__ list_out, int32_t* __restrict__ flag_in,
                                                     int32_t* __restrict__ flag_out) {
     static_assert(PT_W == 32 && PT_N % 64 == 0, "wave-per-tile push kernel: 32-pixel tile rows");
@@ -751,8 +759,11 @@ __global__ void __launch_bounds__(256) k_mf_pr_wave(GcDims d, MfTiles tl, int ph
         nbm = mf_wave_or(nbm | (left ? 1 << 4 : 0));                       // bit 4: this tile still has work
         if (lane < 9 && (nbm >> lane) & 1) {
             const int ty = tyi + lane / 3 - 1, tx = txi + lane % 3 - 1;    // (a push never leaves the image: those arcs have no capacity)
-            if (ty >= 0 && ty < tl.pt_y && tx >= 0 && tx < tl.pt_x)
-                push_tile_l(b * tiles_per_image + ty * tl.pt_x + tx, flag_out, outl, list_out, n_out);
+            if (ty >= 0 && ty < tl.pt_y && tx >= 0 && tx < tl.pt_x) {
+                const int nbt = b * tiles_per_image + ty * tl.pt_x + tx;
+                if (lane != 4) dirty[nbt] = 1;                             // its border arcs may have been re-opened (ggc_mf_sweep.h)
+                push_tile_l(nbt, flag_out, outl, list_out, n_out);
+            }
         }
         mf_wave_sync();
         if (PROF) {      // GGC_MF_TRACE: where a visit's time goes (wall_clock64 ticks at 100 MHz), kept in registers until the wave ends
@@ -857,13 +868,16 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     const size_t ring_cap = std::max(n_rt, n_pt);
     unsigned long long* ring = nullptr;
     int32_t *aq = nullptr, *busy = nullptr;
-    if (async_relax || async_push_active > 0) {
+    {   // (allocated whatever the knobs say: the dirty flags and the trace clocks live in the same block)
         GGC_REQUIRE(ctx, ring_cap < (1u << 24), GGC_E_UNSUPPORTED, "batch has more max-flow tiles than a queue entry addresses");
-        ring = scratch_t<unsigned long long>(ctx, S_GC_O, ring_cap + (AQ_WORDS + n_pt + 1) / 2 + 1 + 128 * 8 + 2);
+        ring = scratch_t<unsigned long long>(ctx, S_GC_O, ring_cap + (AQ_WORDS + n_pt + 1) / 2 + 1 + 128 * 8 + 2 + (n_pt + 1) / 2 + 1);
         if (!ring) return GGC_E_OOM;
         aq = reinterpret_cast<int32_t*>(ring + ring_cap);
         busy = aq + AQ_WORDS;
     }
+    // one word per push tile: a neighbour pushed into it since its arc masks were last exact (k_build_graph has just written them)
+    int32_t* dirty = busy + ((n_pt + 3) & ~(size_t)1) + 2 * 128 * 8;
+    GGC_HIP(ctx, hipMemsetAsync(dirty, 0, sizeof(int32_t) * n_pt, st));
     std::vector<int32_t> host;
     long long* prof_dev = nullptr;                                         // GGC_MF_TRACE: visit-phase clocks of k_mf_pr_wave
     if (std::getenv("GGC_MF_TRACE") != nullptr && ring) {
@@ -919,12 +933,12 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
                 // the first launches relax every tile of the open images (bandwidth work, plain stores); the long sparse rest of
                 // the front runs asynchronously inside one launch that ends at the fixpoint: nothing to read back
                 for (; phase < relax_dense; ++phase)
-                    if (trace && prof_dev) hipLaunchKernelGGL(k_mf_relax_wave<true>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, rc, dist, rl_cnt,
+                    if (trace && prof_dev) hipLaunchKernelGGL(k_mf_relax_wave<true>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt,
                                        rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
-                    else hipLaunchKernelGGL(k_mf_relax_wave<false>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, rc, dist, rl_cnt,
+                    else hipLaunchKernelGGL(k_mf_relax_wave<false>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt,
                                        rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
                 const int grid = (int)std::min<size_t>(async_grid * scale, std::max<size_t>(16, cdiv((size_t)n_cur * tl.rt_x * tl.rt_y, 16)));
-                if ((rcode = maxflow_relax_async(ctx, st, d, tl, rmask, rc, dist, rl_cnt + phase % 3, rl_list[phase & 1], rl_flag[phase & 1], ring, aq,
+                if ((rcode = maxflow_relax_async(ctx, st, d, tl, rmask, dirty, rc, dist, rl_cnt + phase % 3, rl_list[phase & 1], rl_flag[phase & 1], ring, aq,
                                                  (int)n_rt, grid, err_flag)))
                     return rcode;
                 relax_launches = phase + 1;
@@ -932,9 +946,9 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             for (int guard = 0; guard < 100000; ++guard) {
                 for (int rep = 0; rep < relax_rep; ++rep, ++phase) {
                     if (relax_wave)
-                        if (trace && prof_dev) hipLaunchKernelGGL(k_mf_relax_wave<true>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, rc, dist, rl_cnt,
+                        if (trace && prof_dev) hipLaunchKernelGGL(k_mf_relax_wave<true>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt,
                                        rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
-                    else hipLaunchKernelGGL(k_mf_relax_wave<false>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, rc, dist, rl_cnt,
+                    else hipLaunchKernelGGL(k_mf_relax_wave<false>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt,
                                            rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
                     else
                         hipLaunchKernelGGL(k_mf_relax_list, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
@@ -1019,7 +1033,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
                 const int waves = (int)std::min<long long>(4ll * async_grid * (long long)scale, std::max<long long>(64, total_active / 4));
                 static const int gen_tail = env_int("GGC_MF_ASYNC_GEN_TAIL", 24), gen_tail_active = env_int("GGC_MF_ASYNC_GEN_TAIL_ACTIVE", 1000);
                 const int gen_now = total_active <= gen_tail_active ? gen_tail : async_gen;
-                if ((rcode = maxflow_push_async(ctx, st, d, tl, async_th, async_inner, gen_now, rc, ex, snk, dist, rmask, pr_cnt, pt_list[0], (int)n_pt,
+                if ((rcode = maxflow_push_async(ctx, st, d, tl, async_th, async_inner, gen_now, rc, ex, snk, dist, rmask, dirty, pr_cnt, pt_list[0], (int)n_pt,
                                                 busy, ring, aq, waves, err_flag, trace ? prof_dev : nullptr)))
                     return rcode;
                 if (trace) {
@@ -1056,16 +1070,16 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             const int wgrid = (int)std::min<long long>((long long)pr_wgrid_cap * (long long)scale, std::max<long long>(32, (long long)total_active * grid_per_active / 4));
             for (int phase = 0; phase < launches; ++phase) {
                 if (pr_wave && trace)
-                    hipLaunchKernelGGL(k_mf_pr_wave<true>, dim3(wgrid), dim3(256), 0, st, d, tl, phase, sweeps, prof_dev, rc, ex, snk, dist, rmask, pr_cnt,
+                    hipLaunchKernelGGL(k_mf_pr_wave<true>, dim3(wgrid), dim3(256), 0, st, d, tl, phase, sweeps, prof_dev, rc, ex, snk, dist, rmask, dirty, pr_cnt,
                                        pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
                 else if (pr_wave)
-                    hipLaunchKernelGGL(k_mf_pr_wave<false>, dim3(wgrid), dim3(256), 0, st, d, tl, phase, sweeps, prof_dev, rc, ex, snk, dist, rmask, pr_cnt,
+                    hipLaunchKernelGGL(k_mf_pr_wave<false>, dim3(wgrid), dim3(256), 0, st, d, tl, phase, sweeps, prof_dev, rc, ex, snk, dist, rmask, dirty, pr_cnt,
                                        pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
                 else if (ppt == 2)
-                    hipLaunchKernelGGL((k_mf_pr_list<2>), dim3(grid), dim3(PT_N / 2), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, rmask, pr_cnt,
+                    hipLaunchKernelGGL((k_mf_pr_list<2>), dim3(grid), dim3(PT_N / 2), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, rmask, dirty, pr_cnt,
                                        pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
                 else
-                    hipLaunchKernelGGL((k_mf_pr_list<1>), dim3(grid), dim3(PT_N), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, rmask, pr_cnt,
+                    hipLaunchKernelGGL((k_mf_pr_list<1>), dim3(grid), dim3(PT_N), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, rmask, dirty, pr_cnt,
                                        pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
             }
             GGC_LAUNCH_CHECK(ctx);

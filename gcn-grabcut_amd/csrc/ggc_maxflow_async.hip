@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_aq_init(const int32_t* __restrict__ cou
 // ---- global relabel, asynchronous ---------------------------------------------------------------------------------
 struct RelaxWaveLds { int d[RT + 2][RT + 2]; uint32_t m[RT][RT / 4]; };
 
-__global__ void __launch_bounds__(256) k_mf_relax_async(GcDims d, MfTiles tl, const uint8_t* __restrict__ rmask,
+__global__ void __launch_bounds__(256) k_mf_relax_async(GcDims d, MfTiles tl, uint8_t* __restrict__ rmask, int32_t* __restrict__ dirty,
                                                         const int32_t* __restrict__ rc, int32_t* __restrict__ dist, int32_t* __restrict__ flag,
                                                         unsigned long long* __restrict__ ring, int32_t* __restrict__ q, int cap,
                                                         int32_t* __restrict__ err_flag) {
@@ -137,13 +137,15 @@ __global__ void __launch_bounds__(256) k_mf_relax_async(GcDims d, MfTiles tl, co
 #pragma unroll
         for (int r = 0; r < 16; ++r)                                       // arc masks do not change during a relabel: plain loads
             mv[r] = rmask[base + (size_t)min(ty0 + 16 * h + r, d.H - 1) * d.W + min(tx0 + lx, d.W - 1)];
+        const bool dirty_t = mf_tile_dirty(dirty, tl, b, tyi, txi, lane);  // wave-uniform (ggc_mf_sweep.h)
         MfBorderArcs ba;                                                   // (capacities do not change during a relabel either)
-        ba.load(d, rc, (size_t)d.B * d.P, base, ty0, tx0, lx, h);
+        if (dirty_t) ba.load(d, rc, (size_t)d.B * d.P, base, ty0, tx0, lx, h);
         uint32_t inv_v[4] = {0u, 0u, 0u, 0u}, inv_h[4];                    // bit set = no arc; outside the image: all blocked
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const uint32_t m = (tx0 + lx < d.W && ty0 + 16 * h + r < d.H) ? ba.row(~mv[r] & 0xffu, r) : 0xffu;
-            sm[(16 * h + r) * T + lx] = (uint8_t)m;
+            uint32_t m = ~mv[r] & 0xffu;
+            if (dirty_t) m = ba.row(m, r);
+            sm[(16 * h + r) * T + lx] = (uint8_t)((tx0 + lx < d.W && ty0 + 16 * h + r < d.H) ? m : 0xffu);
         }
 #pragma unroll
         for (int k = 0; k < HALO_IT; ++k) {
@@ -152,8 +154,11 @@ __global__ void __launch_bounds__(256) k_mf_relax_async(GcDims d, MfTiles tl, co
             if (i < RT_HALO) sd[i] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? hv[k] : DINF;
         }
         mf_wave_sync();
-        if (ty0 + lx < d.H && tx0 + (h ? 31 : 0) < d.W) sm[lx * T + (h ? 31 : 0)] = (uint8_t)ba.col(sm[lx * T + (h ? 31 : 0)], h);
-        mf_wave_sync();
+        if (dirty_t) {      // (a second wave relaxing the same tile meanwhile writes the same bytes)
+            if (ty0 + lx < d.H && tx0 + (h ? 31 : 0) < d.W) sm[lx * T + (h ? 31 : 0)] = (uint8_t)ba.col(sm[lx * T + (h ? 31 : 0)], h);
+            mf_wave_sync();
+            mf_tile_repair(d, tl, rmask, dirty, S, base, b, tyi, txi, ty0, tx0, lx, h, lane);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) inv_v[r >> 2] |= (uint32_t)sm[(16 * h + r) * T + lx] << (8 * (r & 3));
 #pragma unroll
@@ -400,7 +405,7 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
 }
 
 template <int TH>
-__global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt_y, int inner, int gen_max, int follow, int32_t* __restrict__ rc,
+__global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt_y, int pt_y, int inner, int gen_max, int follow, int32_t* __restrict__ dirty, int32_t* __restrict__ rc,
                                                       int32_t* __restrict__ ex, int32_t* __restrict__ snk, int32_t* __restrict__ dist,
                                                       uint8_t* __restrict__ rmask, int32_t* __restrict__ st, unsigned long long* __restrict__ ring,
                                                       int32_t* __restrict__ q, int cap, int32_t* __restrict__ err_flag,
@@ -450,6 +455,9 @@ __global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt
             const int ty = tyi + lane / 3 - 1, tx = txi + lane % 3 - 1;
             if (ty >= 0 && ty < bt_y && tx >= 0 && tx < bt_x) {
                 nb = b * tiles_per_image + ty * bt_x + tx;
+                // its border arcs may have been re-opened: the 32x8 push tiles it consists of are dirty for the next relabel
+                for (int k = 0; k < TH / PT_H; ++k)
+                    if (ty * (TH / PT_H) + k < pt_y) atomicOr(&dirty[(size_t)b * bt_x * pt_y + (size_t)(ty * (TH / PT_H) + k) * bt_x + tx], 1);
                 cand = (atomicOr(&st[nb], ST_Q) & (ST_Q | ST_BUSY)) == 0;  // idle: ours to arrange; busy: its holder re-queues it
             }
         }
@@ -496,17 +504,17 @@ __global__ void __launch_bounds__(256) k_aq_fill_big(const int32_t* __restrict__
 
 } // namespace
 
-int maxflow_relax_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, const uint8_t* rmask, const int32_t* rc, int32_t* dist,
+int maxflow_relax_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, uint8_t* rmask, int32_t* dirty, const int32_t* rc, int32_t* dist,
                         const int32_t* count, const int32_t* list, int32_t* flag, unsigned long long* ring, int32_t* q, int cap,
                         int grid, int32_t* err_flag) {
     hipLaunchKernelGGL(k_aq_init, dim3(cdiv(cap, 256)), dim3(256), 0, st, count, list, ring, q, cap, 0);
-    hipLaunchKernelGGL(k_mf_relax_async, dim3(grid), dim3(256), 0, st, d, tl, rmask, rc, dist, flag, ring, q, cap, err_flag);
+    hipLaunchKernelGGL(k_mf_relax_async, dim3(grid), dim3(256), 0, st, d, tl, rmask, dirty, rc, dist, flag, ring, q, cap, err_flag);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
 }
 
 int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, int th, int inner, int gen_max, int32_t* rc,
-                       int32_t* ex, int32_t* snk, int32_t* dist, uint8_t* rmask, const int32_t* count, const int32_t* list, int n_list_max, int32_t* state,
+                       int32_t* ex, int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* dirty, const int32_t* count, const int32_t* list, int n_list_max, int32_t* state,
                        unsigned long long* ring, int32_t* q, int waves, int32_t* err_flag, long long* prof) {
     th = th >= 32 ? 32 : (th >= 16 ? 16 : 8);
     const int bt_x = tl.pt_x, bt_y = cdiv(d.H, th), cap = bt_x * bt_y * d.B;
@@ -518,13 +526,13 @@ int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTi
     hipLaunchKernelGGL(k_aq_fill_big, dim3(cdiv(n_list_max, 256)), dim3(256), 0, st, count, list, tl.pt_x, tl.pt_y, th, bt_x, bt_y, state, ring, q,
                        gen_max);
     if (th == 32)
-        hipLaunchKernelGGL(k_mf_push_async<32>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, rmask, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<32>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag, prof);
     else if (th == 8)
-        hipLaunchKernelGGL(k_mf_push_async<8>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, rmask, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<8>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag, prof);
     else
-        hipLaunchKernelGGL(k_mf_push_async<16>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, inner, gen_max, follow, rc, ex, snk, dist, rmask, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<16>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag, prof);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;

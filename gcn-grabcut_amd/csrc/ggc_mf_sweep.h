@@ -78,6 +78,36 @@ struct MfBorderArcs {
     }
 };
 
+// A push tile is DIRTY when a neighbouring tile pushed into it since its masks were last exact (k_build_graph, or a relabel
+// visit that re-read its border arcs): only then can a border bit of rmask be stale, and only then does a relabel visit pay
+// for the 15 border loads — 4 us of its 10 us load phase, the three column loads being 64 scattered lines each.  The visit
+// that re-reads them writes the corrected bytes back and clears the flags (relabel and push phases alternate, nothing moves
+// capacities during a relabel), so later relabels of the solve take the short path until the next push across that edge.
+// dirty: one word per 32x8 push tile.  Returns whether any of the relabel tile's (up to) 4 push tiles is dirty (wave-uniform).
+__device__ __forceinline__ bool mf_tile_dirty(const int32_t* __restrict__ dirty, const MfTiles& tl, int b, int tyi, int txi, int lane) {
+    const int py = tyi * (MF_RT / MF_PT_H) + (lane & 3);
+    const int v = (lane < 4 && py < tl.pt_y) ? dirty[(size_t)b * tl.pt_x * tl.pt_y + (size_t)py * tl.pt_x + txi] : 0;
+    return __any(v != 0);
+}
+// after the row and column patches: the corrected mask bytes of the border pixels go back to rmask, the flags are cleared
+template <class RelaxTile>
+__device__ __forceinline__ void mf_tile_repair(const GcDims& d, const MfTiles& tl, uint8_t* __restrict__ rmask, int32_t* __restrict__ dirty,
+                                               const RelaxTile& S, size_t base, int b, int tyi, int txi, int ty0, int tx0, int lx, int h, int lane) {
+    const uint8_t* sm = reinterpret_cast<const uint8_t*>(&S.m[0][0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (q >> 1) * 8 + ((q & 1) ? 7 : 0);
+        const int y = ty0 + 16 * h + r, x = tx0 + lx;
+        if (x < d.W && y < d.H) rmask[base + (size_t)y * d.W + x] = (uint8_t)(~sm[(16 * h + r) * MF_RT + lx] & 0xffu);
+    }
+    {
+        const int y = ty0 + lx, x = tx0 + (h ? 31 : 0);
+        if (x < d.W && y < d.H) rmask[base + (size_t)y * d.W + x] = (uint8_t)(~sm[lx * MF_RT + (h ? 31 : 0)] & 0xffu);
+    }
+    const int py = tyi * (MF_RT / MF_PT_H) + (lane & 3);
+    if (lane < 4 && py < tl.pt_y) dirty[(size_t)b * tl.pt_x * tl.pt_y + (size_t)py * tl.pt_x + txi] = 0;
+}
+
 // lane = (column lx, half h): pixels (rows 16h .. 16h+15, column lx).  Returns 1 when a label changed.
 template <class RelaxTile>
 __device__ __forceinline__ int relax_sweep_v(RelaxTile& S, const uint32_t (&inv_in)[4], int lx, int h) {
