@@ -223,7 +223,7 @@ struct PushTileLds {
 // Returns the 9-bit mask of tiles owed a visit: bit (dy + 1) * 3 + (dx + 1) for a neighbour that received excess, bit 4
 // when this tile still holds active pixels.
 template <int TH>
-__device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, size_t base, size_t BP,
+__device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, int chase, size_t base, size_t BP,
                                int32_t* __restrict__ rc, int32_t* __restrict__ ex, int32_t* __restrict__ snk,
                                int32_t* __restrict__ dist, uint8_t* __restrict__ rmask, PushTileLds<TH>& S, int lane,
                                bool prof, long long (&pv)[4]) {
@@ -298,14 +298,19 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
         if (lane < TH) S.mask[lane] = 0u;
         while (w) { const int bit = __ffs(w) - 1; S.list[off++] = (unsigned short)(lane * 32 + bit); w &= w - 1; }
         mf_wave_sync();
-        // ---- one active pixel per lane
+        // ---- one active pixel per lane, and the lane CHASES the excess: after a push inside the tile it goes on with the
+        // receiving pixel at once (and after a relabel with the same pixel), up to `chase` steps.  A step is one LDS round trip
+        // (~0.2 us) where a sweep is six (0.94 us), and in the sparse rounds a visit is mostly one or two units of excess
+        // walking across the tile.  Exclusivity: a lane TAKES a pixel's excess with an exchange (two lanes that meet on a pixel:
+        // one gets it all, the other gets zero and drops out) and gives back what it could not push.
         for (int k0 = 0; k0 < n_act; k0 += 64) {
-            const int k = k0 + lane;
-            if (k < n_act) {
-                const int slot = S.list[k], ly = slot >> 5, plx = slot & 31;
-                const int e = __hip_atomic_load(&S.ex[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int dp = S.d[ly + 1][plx + 1];
-                if (e > 0 && dp < d.P) {
+            int slot = k0 + lane < n_act ? (int)S.list[k0 + lane] : -1;
+            for (int step = 0; step < chase; ++step) {
+                if (!__any(slot >= 0)) break;
+                if (slot >= 0) {
+                    const int ly = slot >> 5, plx = slot & 31;
+                    const int e = atomicExch(&S.ex[slot], 0);
+                    const int dp = S.d[ly + 1][plx + 1];
                     const int sk = S.sk[slot];
                     int r[8], hq[8];
 #pragma unroll
@@ -313,45 +318,52 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
                         r[dir] = __hip_atomic_load(&S.rc[dir][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         hq[dir] = S.d[ly + 1 + dir_dy(dir)][plx + 1 + dir_dx(dir)];
                     }
-                    int hmin = sk > 0 ? 0 : DINF, best = sk > 0 ? 8 : -1, rb = 0;
-#pragma unroll
-                    for (int dir = 0; dir < 8; ++dir) {
-                        const bool ok = r[dir] > 0 && hq[dir] < hmin;
-                        hmin = ok ? hq[dir] : hmin; best = ok ? dir : best; rb = ok ? r[dir] : rb;
-                    }
-                    if (best >= 0 && dp > hmin) {
-                        int dl;
-                        if (best == 8) {
-                            dl = min(e, sk);
-                            S.sk[slot] = sk - dl;                      // only this lane touches the pixel's sink link
-                            atomicSub(&S.ex[slot], dl);
-                        } else {
-                            dl = min(e, rb);
-                            atomicSub(&S.rc[best][slot], dl);
-                            atomicSub(&S.ex[slot], dl);
-                            const int qlx = plx + dir_dx(best), qly = ly + dir_dy(best);
-                            if (qlx >= 0 && qlx < 32 && qly >= 0 && qly < TH) {
-                                const int qt = qly * 32 + qlx;
-                                atomicAdd(&S.rc[best ^ 1][qt], dl);
-                                atomicAdd(&S.ex[qt], dl);
-                                atomicOr(&S.mask[qly], 1u << qlx);      // the receiver is looked at in the next sweep
-                            } else {                                    // across the tile edge: straight to memory
-                                const int gy = tyi * TH + qly, gx = txi * 32 + qlx;
-                                const size_t qg = base + (size_t)gy * d.W + gx;
-                                atomicAdd(&rc[rc_idx((best ^ 1), qg)], dl);
-                                atomicAdd(&ex[qg], dl);
-                                const int tdy = qly < 0 ? -1 : (qly >= TH ? 1 : 0), tdx = qlx < 0 ? -1 : (qlx >= 32 ? 1 : 0);
-                                nbm |= 1 << ((tdy + 1) * 3 + tdx + 1);
-                            }
-                        }
-                        if (e - dl > 0) atomicOr(&S.mask[ly], 1u << plx);
+                    if (e <= 0) {
+                        slot = -1;                                     // taken by a lane that walked in, or nothing left
+                    } else if (dp >= d.P) {
+                        atomicAdd(&S.ex[slot], e); slot = -1;          // cannot reach the sink: the excess stays where it is
                     } else {
-                        const int nd = (best >= 0 && hmin < DINF) ? hmin + 1 : DINF;
-                        S.d[ly + 1][plx + 1] = nd;
-                        if (nd < d.P) atomicOr(&S.mask[ly], 1u << plx);
+                        int hmin = sk > 0 ? 0 : DINF, best = sk > 0 ? 8 : -1, rb = 0;
+#pragma unroll
+                        for (int dir = 0; dir < 8; ++dir) {
+                            const bool ok = r[dir] > 0 && hq[dir] < hmin;
+                            hmin = ok ? hq[dir] : hmin; best = ok ? dir : best; rb = ok ? r[dir] : rb;
+                        }
+                        if (best >= 0 && dp > hmin) {
+                            if (best == 8) {
+                                const int dl = min(e, sk);
+                                S.sk[slot] = sk - dl;                  // only the holder of the pixel's excess touches its sink link
+                                if (e - dl > 0) atomicAdd(&S.ex[slot], e - dl); else slot = -1;   // sink link full: on to the neighbours
+                            } else {
+                                const int dl = min(e, rb), rem = e - dl;
+                                atomicSub(&S.rc[best][slot], dl);
+                                if (rem > 0) { atomicAdd(&S.ex[slot], rem); atomicOr(&S.mask[ly], 1u << plx); }   // the rest: next sweep
+                                const int qlx = plx + dir_dx(best), qly = ly + dir_dy(best);
+                                if (qlx >= 0 && qlx < 32 && qly >= 0 && qly < TH) {
+                                    const int qt = qly * 32 + qlx;
+                                    atomicAdd(&S.rc[best ^ 1][qt], dl);
+                                    atomicAdd(&S.ex[qt], dl);
+                                    slot = qt;                          // follow the flow
+                                } else {                                // across the tile edge: straight to memory
+                                    const int gy = tyi * TH + qly, gx = txi * 32 + qlx;
+                                    const size_t qg = base + (size_t)gy * d.W + gx;
+                                    atomicAdd(&rc[rc_idx((best ^ 1), qg)], dl);
+                                    atomicAdd(&ex[qg], dl);
+                                    const int tdy = qly < 0 ? -1 : (qly >= TH ? 1 : 0), tdx = qlx < 0 ? -1 : (qlx >= 32 ? 1 : 0);
+                                    nbm |= 1 << ((tdy + 1) * 3 + tdx + 1);
+                                    slot = rem > 0 ? slot : -1;
+                                }
+                            }
+                        } else {
+                            const int nd = (best >= 0 && hmin < DINF) ? hmin + 1 : DINF;
+                            S.d[ly + 1][plx + 1] = nd;
+                            atomicAdd(&S.ex[slot], e);                 // give it back; with the new label the next step can push
+                            if (nd >= d.P) slot = -1;
+                        }
                     }
                 }
             }
+            if (slot >= 0) atomicOr(&S.mask[slot >> 5], 1u << (slot & 31));     // step limit: the pixel is looked at again next sweep
             mf_wave_sync();
         }
     }
@@ -405,7 +417,7 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, siz
 }
 
 template <int TH>
-__global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt_y, int pt_y, int inner, int gen_max, int follow, int32_t* __restrict__ dirty, int32_t* __restrict__ rc,
+__global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt_y, int pt_y, int inner, int chase, int gen_max, int follow, int32_t* __restrict__ dirty, int32_t* __restrict__ rc,
                                                       int32_t* __restrict__ ex, int32_t* __restrict__ snk, int32_t* __restrict__ dist,
                                                       uint8_t* __restrict__ rmask, int32_t* __restrict__ st, unsigned long long* __restrict__ ring,
                                                       int32_t* __restrict__ q, int cap, int32_t* __restrict__ err_flag,
@@ -440,7 +452,7 @@ __global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt
         const long long t_1 = prof ? wall_clock64() : 0;
         const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
         const int tyi = tr / bt_x, txi = tr % bt_x;
-        const int nbm = push_tile_visit<TH>(d, tyi, txi, inner, (size_t)b * d.P, BP, rc, ex, snk, dist, rmask, S, lane, prof != nullptr, pv);
+        const int nbm = push_tile_visit<TH>(d, tyi, txi, inner, chase, (size_t)b * d.P, BP, rc, ex, snk, dist, rmask, S, lane, prof != nullptr, pv);
         drain();                                                           // the write-back is at memory
         const long long t_2 = prof ? wall_clock64() : 0;
         const bool left = (nbm >> 4) & 1;
@@ -520,19 +532,20 @@ int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTi
     const int bt_x = tl.pt_x, bt_y = cdiv(d.H, th), cap = bt_x * bt_y * d.B;
     gen_max = std::min(gen_max, 127);
     static const int follow = [] { const char* e = std::getenv("GGC_MF_ASYNC_FOLLOW"); return e ? std::atoi(e) : 1; }();
+    static const int chase = [] { const char* e = std::getenv("GGC_MF_ASYNC_CHASE"); return e ? std::max(1, std::atoi(e)) : 1; }();   // > 1 measured slower: most sparse-round excess is trapped and only climbs labels faster
     GGC_HIP(ctx, hipMemsetAsync(ring, 0, sizeof(unsigned long long) * cap, st));
     GGC_HIP(ctx, hipMemsetAsync(q, 0, sizeof(int32_t) * AQ_WORDS, st));
     GGC_HIP(ctx, hipMemsetAsync(state, 0, sizeof(int32_t) * cap, st));
     hipLaunchKernelGGL(k_aq_fill_big, dim3(cdiv(n_list_max, 256)), dim3(256), 0, st, count, list, tl.pt_x, tl.pt_y, th, bt_x, bt_y, state, ring, q,
                        gen_max);
     if (th == 32)
-        hipLaunchKernelGGL(k_mf_push_async<32>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<32>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, chase, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag, prof);
     else if (th == 8)
-        hipLaunchKernelGGL(k_mf_push_async<8>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<8>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, chase, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag, prof);
     else
-        hipLaunchKernelGGL(k_mf_push_async<16>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<16>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, chase, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag, prof);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
