@@ -103,6 +103,23 @@ def clean_mask(mask: np.ndarray, min_area_ratio: float = 0.002, keep_largest: bo
     return eng.clean_mask(m, min_area_ratio, keep_largest)[0].cpu().numpy()
 
 
+def eroded_box(H: int, W: int, bbox: tuple[int, int, int, int], ksize: int = 30) -> tuple[int, int, int, int]:
+    """(y0, y1, x0, x1) of `cv2.erode(box_mask, np.ones((ksize, ksize)))` for the filled box `bbox` = (x, y, w, h) in an H x W
+    image (reference pipeline.py:366-370), in closed form: the kernel's anchor is its centre (ksize // 2), so a pixel survives
+    when the ksize pixels from -ksize // 2 to ksize - 1 - ksize // 2 around it are all inside the box; cv2.erode's default
+    border counts pixels OUTSIDE the image as set, so a side of the box that lies on the image edge is not eroded."""
+    x, y, w, h = bbox
+    a, b = ksize // 2, ksize - 1 - ksize // 2
+    by0, by1, bx0, bx1 = max(y, 0), min(y + h, H), max(x, 0), min(x + w, W)
+    y0 = by0 if by0 == 0 else by0 + a
+    y1 = by1 if by1 == H else by1 - b
+    x0 = bx0 if bx0 == 0 else bx0 + a
+    x1 = bx1 if bx1 == W else bx1 - b
+    if by1 <= by0 or bx1 <= bx0:
+        return 0, 0, 0, 0
+    return y0, y1, x0, x1
+
+
 def _colour_trimap(trimap: np.ndarray) -> np.ndarray:
     """reference pipeline.py:230-236"""
     vis = np.zeros((*trimap.shape, 3), dtype=np.uint8)
@@ -283,8 +300,7 @@ class GCNGrabCutPipeline:
         H, W = image.shape[:2]
         trimap = np.full((H, W), Label.BG_PROBABLE, dtype=np.uint8)
         trimap[y:y + h, x:x + w] = Label.FG_PROBABLE
-        # 30x30 erosion of the box (anchor at the centre, as cv2.erode): shrink by 15 / 14 pixels
-        y0, y1, x0, x1 = max(y, 0) + 15, min(y + h, H) - 14, max(x, 0) + 15, min(x + w, W) - 14
+        y0, y1, x0, x1 = eroded_box(H, W, bbox)
         if y1 > y0 and x1 > x0:
             trimap[y0:y1, x0:x1] = Label.FG_DEFINITE
         return SegmentationResult(image=image, binary_mask=binary_mask, trimap=trimap,
