@@ -39,6 +39,9 @@ constexpr int MF_RT = 32;                          // relabel tile side
 constexpr int MF_PT_W = 32, MF_PT_H = 8;           // push tile
 struct MfTiles { int rt_x, rt_y, pt_x, pt_y; };    // tiles per image
 
+// up to three int32 regions zeroed by one launch on `st` (ggc_maxflow.hip)
+void mf_zero3(hipStream_t st, int32_t* a, size_t na, int32_t* b, size_t nb, int32_t* c, size_t nc);
+
 // Sparse phases as one asynchronous launch each (ggc_maxflow_async.hip): a pool of waves over a ticket queue of tiles.
 // Queue control words (int32, every hot counter on its own 128-byte line):
 constexpr int AQ_HEAD = 0, AQ_TAIL = 32, AQ_PENDING = 64, AQ_DONE = 96, AQ_BUDGET = 97, AQ_VISITS = 128, AQ_WORDS = 160;

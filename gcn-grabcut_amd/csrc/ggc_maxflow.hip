@@ -54,6 +54,18 @@ __device__ __forceinline__ void push_tile(int tile, int32_t* __restrict__ flag, 
     if (ld(&flag[tile]) == 0 && atomicExch(&flag[tile], 1) == 0) list[atomicAdd(count, 1)] = tile;   // cheap test first
 }
 
+// up to three int32 regions zeroed by ONE launch (a round used to issue seven hipMemsetAsync calls: each is a launch of its own)
+__global__ void __launch_bounds__(256) k_mf_zero3(int32_t* __restrict__ a, size_t na, int32_t* __restrict__ b, size_t nb, int32_t* __restrict__ c, size_t nc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < na) a[i] = 0;
+    else if (i < na + nb) b[i - na] = 0;
+    else if (i < na + nb + nc) c[i - na - nb] = 0;
+}
+void mf_zero3(hipStream_t st, int32_t* a, size_t na, int32_t* b, size_t nb, int32_t* c, size_t nc) {
+    const size_t n = na + nb + nc;
+    if (n) hipLaunchKernelGGL(k_mf_zero3, dim3(cdiv(n, 256)), dim3(256), 0, st, a, na, b, nb, c, nc);
+}
+
 // The same through a per-block list.  Every append used to be a returning atomicAdd on the ONE counter of the next list, and
 // same-address atomics retire at ~90 per microsecond chip-wide: a dense launch appends ~15 000 tiles, i.e. >= 150 us of
 // counter traffic — which is what those launches took (139-165 us), whatever the grid or the occupancy.  A block now
@@ -916,10 +928,9 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
         {
             ProfScope prof(ctx, st, "maxflow_relabel");
             const int per_image = tl.rt_x * tl.rt_y;
-            GGC_HIP(ctx, hipMemsetAsync(rl_flag[0], 0, sizeof(int32_t) * n_rt * 2, st));
             static const bool tile_init = env_int0("GGC_MF_TILE_INIT", 1) != 0;
+            mf_zero3(st, rl_flag[0], n_rt * 2, rl_cnt, (relax_wave && tile_init) ? 3 : 0, nullptr, 0);
             if (relax_wave && tile_init) {
-                GGC_HIP(ctx, hipMemsetAsync(rl_cnt, 0, sizeof(int32_t) * 3, st));
                 hipLaunchKernelGGL(k_mf_rinit, dim3(cdiv(per_image, 4), n_cur), dim3(256), 0, st, d, tl, list_cur, snk, dist, rl_list[0], rl_flag[0],
                                    rl_cnt);
             } else {
@@ -961,8 +972,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             }
         }
         // ---- who still has work?  (active pixel = excess that can still reach the sink)
-        GGC_HIP(ctx, hipMemsetAsync(active, 0, sizeof(int32_t) * (B + 8), st));               // active, n_open, all counters, total
-        GGC_HIP(ctx, hipMemsetAsync(pt_flag[0], 0, sizeof(int32_t) * n_pt * 2, st));
+        mf_zero3(st, active, (size_t)B + 8, pt_flag[0], n_pt * 2, nullptr, 0);                // active, n_open, all counters, total | push flags
         hipLaunchKernelGGL(k_mf_active, dim3(std::min(cdiv(d.P, 256 * 4), 128), n_cur), dim3(256), 0, st, d, tl, list_cur, ex, dist,
                            active, pt_flag[0], pt_list[0], pr_cnt);
         hipLaunchKernelGGL(k_done_update, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, n_cur, list_cur, active, list_nxt, n_open);

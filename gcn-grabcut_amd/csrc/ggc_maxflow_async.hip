@@ -533,9 +533,7 @@ int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTi
     gen_max = std::min(gen_max, 127);
     static const int follow = [] { const char* e = std::getenv("GGC_MF_ASYNC_FOLLOW"); return e ? std::atoi(e) : 1; }();
     static const int chase = [] { const char* e = std::getenv("GGC_MF_ASYNC_CHASE"); return e ? std::max(1, std::atoi(e)) : 1; }();   // > 1 measured slower: most sparse-round excess is trapped and only climbs labels faster
-    GGC_HIP(ctx, hipMemsetAsync(ring, 0, sizeof(unsigned long long) * cap, st));
-    GGC_HIP(ctx, hipMemsetAsync(q, 0, sizeof(int32_t) * AQ_WORDS, st));
-    GGC_HIP(ctx, hipMemsetAsync(state, 0, sizeof(int32_t) * cap, st));
+    mf_zero3(st, reinterpret_cast<int32_t*>(ring), (size_t)cap * 2, q, AQ_WORDS, state, (size_t)cap);
     hipLaunchKernelGGL(k_aq_fill_big, dim3(cdiv(n_list_max, 256)), dim3(256), 0, st, count, list, tl.pt_x, tl.pt_y, th, bt_x, bt_y, state, ring, q,
                        gen_max);
     if (th == 32)
