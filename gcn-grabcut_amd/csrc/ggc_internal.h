@@ -41,6 +41,7 @@ struct Buf {
 // key, device copies (raw + packed layouts) built lazily before a forward.
 struct ResgcnWeights {
     int D = 0, n_layers = 0, Q = 0, C = 0;
+    int Dt = 0;                            // true hidden width (ResGCNNet): D is Dt rounded up to a multiple of 32
     std::map<std::string, std::vector<float>> host;
     std::map<std::string, Buf> dev;
     bool dev_ok = false;

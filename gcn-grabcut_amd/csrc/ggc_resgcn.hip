@@ -119,8 +119,12 @@ struct InputW {
     const float *pb_w0 /*[Q,3]*/, *pb_b0, *pb_w2T /*[Q][D]*/, *pb_b2;
 };
 
+// Dt: the model's true width.  D is Dt rounded up to a multiple of 32 (MFMA tiling); the padded channels carry exact zeros
+// through every layer (zero weight rows / columns, zero LayerNorm weights), so only the LayerNorm STATISTICS need to know
+// Dt: the sum over D equals the sum over Dt, the mean divides by Dt, and the squared deviations of the padded channels
+// (each mean^2) are left out.
 template <int D>
-__global__ void __launch_bounds__(256) k_input(int N, const float* __restrict__ x, InputW w, int Q,
+__global__ void __launch_bounds__(256) k_input(int N, const float* __restrict__ x, InputW w, int Q, int Dt,
                                                float* __restrict__ h) {
     constexpr int NC = (D + 63) / 64;
     const int lane = threadIdx.x & 63;
@@ -146,14 +150,14 @@ __global__ void __launch_bounds__(256) k_input(int N, const float* __restrict__ 
             }
             a[j] = acc;
         }
-        const float mean = wave_sum(s1) / (float)D;
+        const float mean = wave_sum(s1) / (float)Dt;
         float s2 = 0.0f;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
             const int c = lane + 64 * j;
-            if (c < D) { const float d = a[j] - mean; s2 += d * d; }
+            if (c < Dt) { const float d = a[j] - mean; s2 += d * d; }
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)D + 1e-5f);
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)Dt + 1e-5f);
         // prior booster hidden unit on lane q < Q
         const float p0 = xi[IN_CH - 3], p1 = xi[IN_CH - 2], p2 = xi[IN_CH - 1];
         float bq = 0.0f;
@@ -275,6 +279,7 @@ struct GemmArgs {
     const float *ep_w, *ep_b;        // MODE 1: LN weight/bias; MODE 2: head weight [3,D] / bias [3]
     float *out, *out2;               // MODE 2: logits / probs (either may be null)
     int accumulate = 0;              // MODE 3: out += A W^T instead of out = A W^T
+    int Dt = 0;                      // true width for the LayerNorm statistics (0: D), see k_input
 };
 
 template <int D, int MODE>
@@ -318,12 +323,13 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
 #pragma unroll
             for (int s = 0; s < KH; ++s) s1 += a[s];
             s1 += __shfl_xor(s1, 32, 64);
-            const float mean = s1 / (float)D;
+            const int dt = g.Dt > 0 ? g.Dt : D, nv = min(max(dt - hk * KH, 0), KH);   // this lane's channels below the true width
+            const float mean = s1 / (float)dt;
             float s2 = 0.0f;
 #pragma unroll
-            for (int s = 0; s < KH; ++s) { const float d = a[s] - mean; s2 += d * d; }
+            for (int s = 0; s < KH; ++s) { const float d = a[s] - mean; s2 += (s < nv) ? d * d : 0.0f; }
             s2 += __shfl_xor(s2, 32, 64);
-            const float rstd = 1.0f / sqrtf(s2 / (float)D + 1e-5f);
+            const float rstd = 1.0f / sqrtf(s2 / (float)dt + 1e-5f);
             const float* lw = g.ln_w + hk * KH;
             const float* lb = g.ln_b + hk * KH;
 #pragma unroll
@@ -375,13 +381,14 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
             for (int t = 0; t < T; ++t) { acc[t][r] += bias[t]; s1 += acc[t][r]; }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
-            const float mean = s1 / (float)D;
+            const int dt = g.Dt > 0 ? g.Dt : D;
+            const float mean = s1 / (float)dt;
             float s2 = 0.0f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) { const float d = acc[t][r] - mean; s2 += d * d; }
+            for (int t = 0; t < T; ++t) { const float d = acc[t][r] - mean; s2 += (32 * t + li < dt) ? d * d : 0.0f; }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-            const float rstd = 1.0f / sqrtf(s2 / (float)D + 1e-5f);
+            const float rstd = 1.0f / sqrtf(s2 / (float)dt + 1e-5f);
             const int grow = r0 + (r & 3) + 8 * (r >> 2) + 4 * hk;
             if (grow < N) {
 #pragma unroll
@@ -902,37 +909,50 @@ static std::vector<float> pack_mfma(const std::vector<float>& w, int D) {
     return p;
 }
 
-struct Need { std::string key; int64_t numel; };
+// A state_dict entry: true shape [rows, cols] (cols = 1: a vector) and the shape of its device copy, where every dimension
+// that is the hidden width Dt is zero-padded to D (the multiple of 32 the kernels are built for).
+struct Need { std::string key; int64_t numel; int r = 0, c = 1, rp = 0, cp = 1; };
 
 static std::vector<Need> needed(const ResgcnWeights& m) {
-    const int D = m.D, Q = m.Q, C = m.C, n = m.n_layers;
-    std::vector<Need> v = {
-        {"in_norm.norm.weight", IN_CH}, {"in_norm.norm.bias", IN_CH},
-        {"in_norm.norm.running_mean", IN_CH}, {"in_norm.norm.running_var", IN_CH},
-        {"input_proj.0.weight", (int64_t)D * IN_CH}, {"input_proj.0.bias", D},
-        {"input_proj.1.weight", D}, {"input_proj.1.bias", D},
-        {"prior_booster.0.weight", (int64_t)Q * N_PRIOR}, {"prior_booster.0.bias", Q},
-        {"prior_booster.2.weight", (int64_t)D * Q}, {"prior_booster.2.bias", D},
-        {"edge_ctx.encode.0.weight", (int64_t)C * EDGE_CH}, {"edge_ctx.encode.0.bias", C},
-        {"edge_ctx.encode.2.weight", (int64_t)C * C}, {"edge_ctx.encode.2.bias", C},
-        {"edge_ctx.to_gate.0.weight", C}, {"edge_ctx.to_gate.0.bias", C},
-        {"edge_ctx.to_gate.1.weight", (int64_t)D * C}, {"edge_ctx.to_gate.1.bias", D},
-        {"sage.lin_l.weight", (int64_t)D * D}, {"sage.lin_l.bias", D}, {"sage.lin_r.weight", (int64_t)D * D},
-        {"sage_norm.weight", D}, {"sage_norm.bias", D}, {"jk_logits", n + 2},
-        {"ctx.attn.weight", D}, {"ctx.attn.bias", 1},
-        {"ctx.compress.weight", (int64_t)(D / 2) * D}, {"ctx.compress.bias", D / 2},
-        {"ctx.expand.weight", (int64_t)D * (D / 2)}, {"ctx.expand.bias", D},
-        {"fuse.0.weight", D}, {"fuse.0.bias", D}, {"fuse.1.weight", (int64_t)D * D}, {"fuse.1.bias", D},
-        {"head.weight", (int64_t)N_CLS * D}, {"head.bias", N_CLS},
-    };
+    const int D = m.D, Dt = m.Dt > 0 ? m.Dt : m.D, Q = m.Q, C = m.C, n = m.n_layers;
+    std::vector<Need> v;
+    auto add = [&](const std::string& k, int r, int c, int rp, int cp) { v.push_back({k, (int64_t)r * c, r, c, rp, cp}); };
+    auto vec = [&](const std::string& k, int len) { add(k, len, 1, len, 1); };
+    auto vecD = [&](const std::string& k) { add(k, Dt, 1, D, 1); };
+    vec("in_norm.norm.weight", IN_CH); vec("in_norm.norm.bias", IN_CH);
+    vec("in_norm.norm.running_mean", IN_CH); vec("in_norm.norm.running_var", IN_CH);
+    add("input_proj.0.weight", Dt, IN_CH, D, IN_CH); vecD("input_proj.0.bias");
+    vecD("input_proj.1.weight"); vecD("input_proj.1.bias");
+    add("prior_booster.0.weight", Q, N_PRIOR, Q, N_PRIOR); vec("prior_booster.0.bias", Q);
+    add("prior_booster.2.weight", Dt, Q, D, Q); vecD("prior_booster.2.bias");
+    add("edge_ctx.encode.0.weight", C, EDGE_CH, C, EDGE_CH); vec("edge_ctx.encode.0.bias", C);
+    add("edge_ctx.encode.2.weight", C, C, C, C); vec("edge_ctx.encode.2.bias", C);
+    vec("edge_ctx.to_gate.0.weight", C); vec("edge_ctx.to_gate.0.bias", C);
+    add("edge_ctx.to_gate.1.weight", Dt, C, D, C); vecD("edge_ctx.to_gate.1.bias");
+    add("sage.lin_l.weight", Dt, Dt, D, D); vecD("sage.lin_l.bias"); add("sage.lin_r.weight", Dt, Dt, D, D);
+    vecD("sage_norm.weight"); vecD("sage_norm.bias"); vec("jk_logits", n + 2);
+    vecD("ctx.attn.weight"); vec("ctx.attn.bias", 1);
+    add("ctx.compress.weight", Dt / 2, Dt, D / 2, D); add("ctx.compress.bias", Dt / 2, 1, D / 2, 1);
+    add("ctx.expand.weight", Dt, Dt / 2, D, D / 2); vecD("ctx.expand.bias");
+    vecD("fuse.0.weight"); vecD("fuse.0.bias"); add("fuse.1.weight", Dt, Dt, D, D); vecD("fuse.1.bias");
+    add("head.weight", N_CLS, Dt, N_CLS, D); vec("head.bias", N_CLS);
     for (int i = 0; i < n; ++i) {
         const std::string s = std::to_string(i);
-        v.push_back({"gcn_layers." + s + ".bias", D});
-        v.push_back({"gcn_layers." + s + ".lin.weight", (int64_t)D * D});
-        v.push_back({"norms." + s + ".weight", D});
-        v.push_back({"norms." + s + ".bias", D});
+        vecD("gcn_layers." + s + ".bias");
+        add("gcn_layers." + s + ".lin.weight", Dt, Dt, D, D);
+        vecD("norms." + s + ".weight");
+        vecD("norms." + s + ".bias");
     }
     return v;
+}
+
+// zero-padded copy [rp, cp] of a row-major [r, c] array
+static std::vector<float> pad2(const std::vector<float>& w, const Need& nd) {
+    if (nd.r == nd.rp && nd.c == nd.cp) return w;
+    std::vector<float> p((size_t)nd.rp * nd.cp, 0.0f);
+    for (int i = 0; i < nd.r; ++i)
+        for (int j = 0; j < nd.c; ++j) p[(size_t)i * nd.cp + j] = w[(size_t)i * nd.c + j];
+    return p;
 }
 
 static int check_ready(ggc_ctx* ctx) {
@@ -957,20 +977,23 @@ static int prepare_weights(ggc_ctx* ctx) {
     // the (non-blocking) stream a previous forward may still be running on: drain the device first.  Weight changes are rare.
     GGC_HIP(ctx, hipDeviceSynchronize());
     const int D = m.D, Q = m.Q, C = m.C, n = m.n_layers;
-    for (auto& kv : m.host) { rc = upload(ctx, kv.first, kv.second); if (rc) return rc; }
-    if ((rc = upload(ctx, "#input_proj.0.weightT", transpose(m.host["input_proj.0.weight"], D, IN_CH)))) return rc;
-    if ((rc = upload(ctx, "#prior_booster.2.weightT", transpose(m.host["prior_booster.2.weight"], D, Q)))) return rc;
-    if ((rc = upload(ctx, "#edge_ctx.encode.2.weightT", transpose(m.host["edge_ctx.encode.2.weight"], C, C)))) return rc;
-    if ((rc = upload(ctx, "#edge_ctx.to_gate.1.weightT", transpose(m.host["edge_ctx.to_gate.1.weight"], D, C)))) return rc;
-    if ((rc = upload(ctx, "#ctx.compress.weightT", transpose(m.host["ctx.compress.weight"], D / 2, D)))) return rc;
-    if ((rc = upload(ctx, "#ctx.expand.weightT", transpose(m.host["ctx.expand.weight"], D, D / 2)))) return rc;
+    // device copies are the zero-padded arrays (a width that is a multiple of 32 pads nothing); m.host keeps what was loaded
+    std::map<std::string, std::vector<float>> pw;
+    for (const Need& nd : needed(m)) pw[nd.key] = pad2(m.host[nd.key], nd);
+    for (auto& kv : pw) { rc = upload(ctx, kv.first, kv.second); if (rc) return rc; }
+    if ((rc = upload(ctx, "#input_proj.0.weightT", transpose(pw["input_proj.0.weight"], D, IN_CH)))) return rc;
+    if ((rc = upload(ctx, "#prior_booster.2.weightT", transpose(pw["prior_booster.2.weight"], D, Q)))) return rc;
+    if ((rc = upload(ctx, "#edge_ctx.encode.2.weightT", transpose(pw["edge_ctx.encode.2.weight"], C, C)))) return rc;
+    if ((rc = upload(ctx, "#edge_ctx.to_gate.1.weightT", transpose(pw["edge_ctx.to_gate.1.weight"], D, C)))) return rc;
+    if ((rc = upload(ctx, "#ctx.compress.weightT", transpose(pw["ctx.compress.weight"], D / 2, D)))) return rc;
+    if ((rc = upload(ctx, "#ctx.expand.weightT", transpose(pw["ctx.expand.weight"], D, D / 2)))) return rc;
     for (int i = 0; i < n; ++i) {
         const std::string k = "gcn_layers." + std::to_string(i) + ".lin.weight";
-        if ((rc = upload(ctx, "#" + k + ".p", pack_mfma(m.host[k], D)))) return rc;
+        if ((rc = upload(ctx, "#" + k + ".p", pack_mfma(pw[k], D)))) return rc;
     }
-    if ((rc = upload(ctx, "#sage.lin_l.weight.p", pack_mfma(m.host["sage.lin_l.weight"], D)))) return rc;
-    if ((rc = upload(ctx, "#sage.lin_r.weight.p", pack_mfma(m.host["sage.lin_r.weight"], D)))) return rc;
-    if ((rc = upload(ctx, "#fuse.1.weight.p", pack_mfma(m.host["fuse.1.weight"], D)))) return rc;
+    if ((rc = upload(ctx, "#sage.lin_l.weight.p", pack_mfma(pw["sage.lin_l.weight"], D)))) return rc;
+    if ((rc = upload(ctx, "#sage.lin_r.weight.p", pack_mfma(pw["sage.lin_r.weight"], D)))) return rc;
+    if ((rc = upload(ctx, "#fuse.1.weight.p", pack_mfma(pw["fuse.1.weight"], D)))) return rc;
     {   // softmax(jk_logits) on the host (model.py:532), same op order as the oracle
         const std::vector<float>& jl = m.host["jk_logits"];
         std::vector<float> w(jl.size());
@@ -1115,7 +1138,7 @@ static int forward_t(ggc_ctx* ctx, hipStream_t st, int G, int N, int E, const fl
                  devp(ctx, "input_proj.1.weight"), devp(ctx, "input_proj.1.bias"),
                  devp(ctx, "prior_booster.0.weight"), devp(ctx, "prior_booster.0.bias"),
                  devp(ctx, "#prior_booster.2.weightT"), devp(ctx, "prior_booster.2.bias")};
-        hipLaunchKernelGGL((k_input<D>), dim3(wave_blocks), dim3(256), 0, st, N, x, w, m.Q, states);
+        hipLaunchKernelGGL((k_input<D>), dim3(wave_blocks), dim3(256), 0, st, N, x, w, m.Q, m.Dt, states);
         GGC_LAUNCH_CHECK(ctx);
     }
     {
@@ -1134,7 +1157,7 @@ static int forward_t(ggc_ctx* ctx, hipStream_t st, int G, int N, int E, const fl
         GemmArgs a{};
         a.A1 = h_in; a.Wp1 = devp(ctx, "#gcn_layers." + s + ".lin.weight.p");
         a.ln_w = devp(ctx, "norms." + s + ".weight"); a.ln_b = devp(ctx, "norms." + s + ".bias");
-        a.out = xw;
+        a.out = xw; a.Dt = m.Dt;
         if ((rc = launch_gemm<D, 0>(ctx, st, N, a))) return rc;
         if ((rc = launch_aggregate<D, 0>(ctx, st, N, xw, row_ptr, col, dis, devp(ctx, "gcn_layers." + s + ".bias"),
                                          gate, h_in, h_out, ag)))
@@ -1149,7 +1172,7 @@ static int forward_t(ggc_ctx* ctx, hipStream_t st, int G, int N, int E, const fl
         a.Wp1 = devp(ctx, "#sage.lin_l.weight.p"); a.Wp2 = devp(ctx, "#sage.lin_r.weight.p");
         a.bias = devp(ctx, "sage.lin_l.bias");
         a.ep_w = devp(ctx, "sage_norm.weight"); a.ep_b = devp(ctx, "sage_norm.bias");
-        a.out = states + ND * (n + 1);
+        a.out = states + ND * (n + 1); a.Dt = m.Dt;
         if ((rc = launch_gemm<D, 1>(ctx, st, N, a))) return rc;
     }
     hipLaunchKernelGGL((k_jk<D>), dim3(cdiv(N, AggCfg<D>::RPB)), dim3(256), 0, st, N, n_states, states,
@@ -1168,7 +1191,7 @@ static int forward_t(ggc_ctx* ctx, hipStream_t st, int G, int N, int E, const fl
         a.bias = devp(ctx, "fuse.1.bias");
         a.batch = batch; a.gvec = gvec;
         a.ep_w = devp(ctx, "head.weight"); a.ep_b = devp(ctx, "head.bias");
-        a.out = logits; a.out2 = probs;
+        a.out = logits; a.out2 = probs; a.Dt = m.Dt;
         if ((rc = launch_gemm<D, 2>(ctx, st, N, a))) return rc;
     }
     return GGC_OK;
@@ -1182,12 +1205,13 @@ extern "C" {
 
 int ggc_resgcn_configure(ggc_ctx* ctx, int hidden, int n_layers) {
     if (!ctx) return GGC_E_INVALID_ARG;
-    GGC_REQUIRE(ctx, hidden == 32 || hidden == 64 || hidden == 96 || hidden == 128, GGC_E_UNSUPPORTED,
-                "hidden_channels=%d unsupported: the MFMA tiling needs a multiple of 32 up to 128", hidden);
+    GGC_REQUIRE(ctx, hidden >= 8 && hidden <= 128, GGC_E_UNSUPPORTED,
+                "hidden_channels=%d unsupported: the kernels are built for widths from 8 to 128", hidden);
     GGC_REQUIRE(ctx, n_layers >= 1 && n_layers <= 30, GGC_E_INVALID_ARG, "n_layers=%d out of range [1,30]", n_layers);
     ResgcnWeights& m = ctx->model;
-    if (m.D != hidden || m.n_layers != n_layers) { m.host.clear(); }
-    m.D = hidden; m.n_layers = n_layers;
+    if (m.Dt != hidden || m.n_layers != n_layers) { m.host.clear(); }
+    // widths that are not a multiple of 32 run zero-padded to the next one (k_input: only the LayerNorm statistics see Dt)
+    m.Dt = hidden; m.D = (hidden + 31) / 32 * 32; m.n_layers = n_layers;
     m.Q = hidden / 4 > 8 ? hidden / 4 : 8;   // model.py:472
     m.C = hidden / 2 > 8 ? hidden / 2 : 8;   // model.py:123
     m.dev_ok = false;
@@ -1210,7 +1234,7 @@ int ggc_resgcn_load_weight(ggc_ctx* ctx, const char* name, const float* data, in
             break;
         }
     GGC_REQUIRE(ctx, known, GGC_E_INVALID_ARG, "unexpected state_dict key '%s' for ResGCNNet(D=%d, n=%d)", name,
-                ctx->model.D, ctx->model.n_layers);
+                ctx->model.Dt, ctx->model.n_layers);
     ctx->model.host[key].assign(data, data + numel);
     ctx->model.dev_ok = false;
     return GGC_OK;

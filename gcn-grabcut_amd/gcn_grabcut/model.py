@@ -100,8 +100,9 @@ if _TORCH:
                     "the MI355X kernels are specialised for the reference's fixed widths: "
                     f"in_channels={N_NODE_FEATS}, edge_channels={N_EDGE_FEATS}, n_classes=3"
                 )
-            if hidden_channels not in (32, 64, 96, 128):
-                raise ValueError("hidden_channels must be 32, 64, 96 or 128 (MFMA tiling)")
+            if not 8 <= int(hidden_channels) <= 128:
+                raise ValueError("hidden_channels must lie in [8, 128] (the HIP kernels are built for widths up to 128; widths that "
+                                 "are not a multiple of 32 run zero-padded inside the library)")
             self.n_classes = n_classes
             self.n_layers = n_layers
             self.hidden_channels = hidden_channels

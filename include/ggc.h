@@ -154,6 +154,8 @@ int ggc_graph_prior_sigmas(ggc_ctx* ctx, double centre_sigma, double contrast_si
  * one state_dict entry by its reference key, e.g.
  * "gcn_layers.3.lin.weight", as a contiguous f32 HOST array.  Integer buffers
  * ("...num_batches_tracked") are accepted and ignored.
+ * hidden: any width from 8 to 128 (model.py:449-455 takes any); the entries are given in their TRUE shapes.  A width that is
+ * not a multiple of 32 runs zero-padded to the next one inside the library (LayerNorm statistics on the true width).
  */
 int ggc_resgcn_configure(ggc_ctx* ctx, int hidden, int n_layers);
 int ggc_resgcn_load_weight(ggc_ctx* ctx, const char* name, const float* data /*[host]*/,

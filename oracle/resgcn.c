@@ -88,14 +88,22 @@ static void ln_stats_wave(const float* x, int D, float* mean_out, float* rstd_ou
     *rstd_out = 1.0f / sqrtf(butterfly(v, 64) / (float)D + 1e-5f);
 }
 
+/* A width that is not a multiple of 32 runs zero-padded to the next one on the MI355X (the MFMA tiling), with the LayerNorm
+ * statistics kept on the true width (csrc/ggc_resgcn.hip, k_input).  The sums below therefore split the row at HALF THE PADDED
+ * width, as the kernels do; the padded channels are exact zeros and drop out of every sum (x + 0 = x). */
+static int padded_width(int D) { return (D + 31) / 32 * 32; }
+
 /* LayerNorm of k_gemm's prologue: each half of the row summed in order, then the two halves added */
 static void layernorm_halves(const float* x, const float* w, const float* b, int D, float* y) {
-    const int KH = D / 2;
+    const int KH = padded_width(D) / 2;
     float s0 = 0.0f, s1 = 0.0f;
-    for (int k = 0; k < KH; ++k) { s0 += x[k]; s1 += x[KH + k]; }
+    for (int k = 0; k < KH; ++k) { if (k < D) s0 += x[k]; if (KH + k < D) s1 += x[KH + k]; }
     const float mean = (s0 + s1) / (float)D;
     float q0 = 0.0f, q1 = 0.0f;
-    for (int k = 0; k < KH; ++k) { const float d0 = x[k] - mean, d1 = x[KH + k] - mean; q0 += d0 * d0; q1 += d1 * d1; }
+    for (int k = 0; k < KH; ++k) {
+        if (k < D) { const float d0 = x[k] - mean; q0 += d0 * d0; }
+        if (KH + k < D) { const float d1 = x[KH + k] - mean; q1 += d1 * d1; }
+    }
     const float rstd = 1.0f / sqrtf((q0 + q1) / (float)D + 1e-5f);
     for (int k = 0; k < D; ++k) y[k] = (x[k] - mean) * rstd * w[k] + b[k];
 }
@@ -112,11 +120,14 @@ static void ln_stats_cols32(const float* x, int D, float* mean_out, float* rstd_
 
 /* acc[o] = fma chain over k of a[k] W[o,k] in the matrix pipe's order (see the header), continuing from acc[] */
 static void mfma_row(const float* a, const float* W, int D, float* acc) {
-    const int KH = D / 2;
+    const int KH = padded_width(D) / 2;
     for (int o = 0; o < D; ++o) {
         const float* w = W + (size_t)o * D;
         float c = acc[o];
-        for (int s_ = 0; s_ < KH; ++s_) { c = fmaf(a[s_], w[s_], c); c = fmaf(a[KH + s_], w[KH + s_], c); }
+        for (int s_ = 0; s_ < KH; ++s_) {
+            if (s_ < D) c = fmaf(a[s_], w[s_], c);
+            if (KH + s_ < D) c = fmaf(a[KH + s_], w[KH + s_], c);
+        }
         acc[o] = c;
     }
 }
@@ -304,17 +315,21 @@ int ggo_resgcn_forward(const float* const* P, int D, int n_layers,
     {
         const float* aw = P[b0 + 6];
         const float* ab = P[b0 + 7];
-        const int LPR = D <= 32 ? 8 : (D <= 64 ? 16 : 32);            /* lanes per row, 4 consecutive channels each */
+        const int Dp = padded_width(D);                                /* the kernels' width: channels >= D are zeros */
+        const int LPR = Dp <= 32 ? 8 : (Dp <= 64 ? 16 : 32);          /* lanes per row, 4 consecutive channels each */
         float* score = (float*)malloc((size_t)N * sizeof(float));
         for (int i = 0; i < N; ++i) {
             float v[32];
             const float* hr = tmp + (size_t)i * D;
-            for (int l = 0; l < LPR; ++l)
-                v[l] = 4 * l < D ? ((hr[4 * l] * aw[4 * l] + hr[4 * l + 1] * aw[4 * l + 1]) + hr[4 * l + 2] * aw[4 * l + 2]) + hr[4 * l + 3] * aw[4 * l + 3] : 0.0f;
+            for (int l = 0; l < LPR; ++l) {
+                float p[4];
+                for (int u = 0; u < 4; ++u) p[u] = 4 * l + u < D ? hr[4 * l + u] * aw[4 * l + u] : 0.0f;
+                v[l] = ((p[0] + p[1]) + p[2]) + p[3];
+            }
             score[i] = butterfly(v, LPR) + ab[0];
         }
         /* graphs are contiguous node ranges (PyG Batch); one 256-thread block per graph */
-        const int NG = 256 / D;
+        const int NG = 256 / Dp;
         float* gs = (float*)malloc((size_t)n_graphs * D * sizeof(float));
         int beg = 0;
         for (int q = 0; q < n_graphs; ++q) {

@@ -35,6 +35,30 @@ def test_forward_matches_oracle(oracle, gpu_ctx, hidden, layers, n):
     assert np.allclose(probs.sum(1), 1.0, atol=1e-6)
 
 
+@pytest.mark.parametrize("hidden,layers,n", [(16, 2, 90), (48, 2, 257), (100, 3, 300), (33, 2, 64), (35, 2, 130), (9, 1, 40)])
+def test_widths_that_are_not_a_multiple_of_32_run_zero_padded(oracle, gpu_ctx, hidden, layers, n):
+    """reference model.py:449-455 takes any width.  The library pads the width to the next multiple of 32 with zeros and keeps
+    the LayerNorm statistics on the true width; the padded channels are exact zeros, so the result is the unpadded model's.
+    The oracle runs at the TRUE width with its sums split where the padded kernels split them: equal bit for bit."""
+    model, sd = seeded_state_dict(hidden, layers, seed=3 * hidden + layers)
+    model = model.to("cuda").eval()
+    assert sum(p.numel() for p in model.parameters()) == sum(v.numel() for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k)
+    x, ei, ea = superpixel_like_graph(n=n, seed=n + 1)
+    want, want_p = oracle.resgcn_forward(_np_state(sd), hidden, layers, x, ei, ea)
+    d = _data(x, ei, ea)
+    got = model(d).cpu().numpy()
+    assert got.shape == (n, 3) and np.isfinite(got).all()
+    assert np.array_equal(got, want), np.abs(got - want).max()       # the oracle splits its sums at half the PADDED width too
+    assert np.array_equal(model.predict_probs(d), want_p)
+    # batched == single, as for the native widths
+    from gcn_grabcut.data import Batch, Data
+    x2, ei2, ea2 = superpixel_like_graph(n=70, seed=5)
+    b = Batch.from_data_list([Data(x=torch.as_tensor(x), edge_index=torch.as_tensor(ei), edge_attr=torch.as_tensor(ea)),
+                              Data(x=torch.as_tensor(x2), edge_index=torch.as_tensor(ei2), edge_attr=torch.as_tensor(ea2))]).to("cuda")
+    both = model(b).cpu().numpy()
+    assert np.array_equal(both[:n], got)
+
+
 def test_two_models_alternate_on_one_context(gpu_ctx):
     """The library context holds ONE set of ResGCN weights: a model must notice that another one replaced its weights
     there (the record of what is resident lives on the context, not on the model)."""

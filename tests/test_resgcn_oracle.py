@@ -40,7 +40,9 @@ def test_state_dict_keys_match_reference_contract():
     assert "sage.lin_r.bias" not in sd and "gcn_layers.0.lin.bias" not in sd
 
 
-@pytest.mark.parametrize("hidden,layers", [(32, 2), (96, 3), (128, 6)])
+# (widths that are not a multiple of 32 or of 4: the oracle splits its sums where the zero-padded kernels do, the values are
+# those of the true width)
+@pytest.mark.parametrize("hidden,layers", [(32, 2), (96, 3), (128, 6), (9, 1), (16, 2), (33, 2), (35, 2), (100, 3), (127, 2)])
 def test_oracle_matches_torch_restatement(oracle, hidden, layers):
     _, sd = seeded_state_dict(hidden, layers, seed=3)
     x, ei, ea = superpixel_like_graph(n=300, seed=5)
