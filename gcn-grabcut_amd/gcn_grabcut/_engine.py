@@ -53,6 +53,8 @@ class Engine:
         max-flow ends in rounds with a handful of open images that are pure launch latency; running sub-batches
         on separate streams lets one sub-batch's tail overlap another's bandwidth-bound rounds."""
         if self._lanes is None or len(self._lanes) != n:
+            if getattr(self, "_pool", None) is not None:
+                self._pool.shutdown(wait=True)       # the lane count changed: the old worker threads end here, not at exit
             self._pool = None
             self._lanes = [(Engine(self.index, private_context=True), torch.cuda.Stream(self.device)) for _ in range(n)]
         return self._lanes
