@@ -32,6 +32,17 @@ __device__ __forceinline__ int relax_px(int c, uint32_t inv, int pos, int lf, in
                          min(gated(ur, inv, pos + 6), gated(dl, inv, pos + 7)));
     return min(c, nd + 1);
 }
+// Five neighbours instead of eight: a pass that walks in one direction looks at the three neighbours it comes from and the two
+// beside it; the opposite pass of the same sweep looks at the other three and the same two.  Together they cover all eight arcs,
+// so a sweep that changes nothing is still a fixpoint test, and the fixpoint (the exact distances) is the same — at 10 gated
+// minima per pixel and sweep instead of 16 (the sweeps are bound by instruction issue: ~1 100 instructions each before).
+// bA..bE: bit offsets of the five arcs inside the pixel's mask byte.
+template <int bA, int bB, int bC, int bD, int bE>
+__device__ __forceinline__ int relax_px5(int c, uint32_t inv, int pos, int vA, int vB, int vC, int vD, int vE) {
+    const int nd = min3i(min3i(gated(vA, inv, pos + bA), gated(vB, inv, pos + bB), gated(vC, inv, pos + bC)),
+                         gated(vD, inv, pos + bD), gated(vE, inv, pos + bE));
+    return min(c, nd + 1);
+}
 
 
 // Arc masks of a 32x32 relabel tile come from rmask (1 byte per pixel, kept current by the push visits for the arcs inside
@@ -122,18 +133,16 @@ __device__ __forceinline__ int relax_sweep_v(RelaxTile& S, const uint32_t (&inv_
         for (int c = 0; c < 3; ++c) w[a][c] = S.d[16 * h + a][lx + c];
     uint32_t chg = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) {                          // downwards: left, right, up, up-left, up-right (bits 0, 1, 2, 4, 6)
         const int a = r + 1;
-        const int nv = relax_px(w[a][1], inv[r >> 2], 8 * (r & 3), w[a][0], w[a][2], w[a - 1][1], w[a + 1][1], w[a - 1][0], w[a + 1][2],
-                                w[a - 1][2], w[a + 1][0]);
+        const int nv = relax_px5<0, 1, 2, 4, 6>(w[a][1], inv[r >> 2], 8 * (r & 3), w[a][0], w[a][2], w[a - 1][1], w[a - 1][0], w[a - 1][2]);
         chg |= (nv != w[a][1]) ? 1u << r : 0u;
         w[a][1] = nv;
     }
 #pragma unroll
-    for (int r = 15; r >= 0; --r) {
+    for (int r = 15; r >= 0; --r) {                         // upwards: left, right, down, down-right, down-left (bits 0, 1, 3, 5, 7)
         const int a = r + 1;
-        const int nv = relax_px(w[a][1], inv[r >> 2], 8 * (r & 3), w[a][0], w[a][2], w[a - 1][1], w[a + 1][1], w[a - 1][0], w[a + 1][2],
-                                w[a - 1][2], w[a + 1][0]);
+        const int nv = relax_px5<0, 1, 3, 5, 7>(w[a][1], inv[r >> 2], 8 * (r & 3), w[a][0], w[a][2], w[a + 1][1], w[a + 1][2], w[a + 1][0]);
         chg |= (nv != w[a][1]) ? 1u << r : 0u;
         w[a][1] = nv;
     }
@@ -154,18 +163,16 @@ __device__ __forceinline__ int relax_sweep_h(RelaxTile& S, const uint32_t (&inv_
         for (int c = 0; c < 18; ++c) w[a][c] = S.d[ly + a][16 * h + c];
     uint32_t chg = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < 16; ++k) {                          // rightwards: up, down, left, up-left, down-left (bits 2, 3, 0, 4, 7)
         const int c = k + 1;
-        const int nv = relax_px(w[1][c], inv[k >> 2], 8 * (k & 3), w[1][c - 1], w[1][c + 1], w[0][c], w[2][c], w[0][c - 1], w[2][c + 1],
-                                w[0][c + 1], w[2][c - 1]);
+        const int nv = relax_px5<2, 3, 0, 4, 7>(w[1][c], inv[k >> 2], 8 * (k & 3), w[0][c], w[2][c], w[1][c - 1], w[0][c - 1], w[2][c - 1]);
         chg |= (nv != w[1][c]) ? 1u << k : 0u;
         w[1][c] = nv;
     }
 #pragma unroll
-    for (int k = 15; k >= 0; --k) {
+    for (int k = 15; k >= 0; --k) {                         // leftwards: up, down, right, up-right, down-right (bits 2, 3, 1, 6, 5)
         const int c = k + 1;
-        const int nv = relax_px(w[1][c], inv[k >> 2], 8 * (k & 3), w[1][c - 1], w[1][c + 1], w[0][c], w[2][c], w[0][c - 1], w[2][c + 1],
-                                w[0][c + 1], w[2][c - 1]);
+        const int nv = relax_px5<2, 3, 1, 6, 5>(w[1][c], inv[k >> 2], 8 * (k & 3), w[0][c], w[2][c], w[1][c + 1], w[0][c + 1], w[2][c + 1]);
         chg |= (nv != w[1][c]) ? 1u << k : 0u;
         w[1][c] = nv;
     }
