@@ -218,12 +218,13 @@ template <int TH>
 struct PushTileLds {
     int ex[32 * TH]; int sk[32 * TH]; int d[TH + 2][34]; int rc[8][32 * TH];
     uint32_t mask[32]; unsigned short list[32 * TH];
+    unsigned char streak[32 * TH];      // relabels in a row without a push (a pixel is handled by one lane at a time)
 };
 
 // Returns the 9-bit mask of tiles owed a visit: bit (dy + 1) * 3 + (dx + 1) for a neighbour that received excess, bit 4
 // when this tile still holds active pixels.
 template <int TH>
-__device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, int chase, size_t base, size_t BP,
+__device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, int chase, int park, size_t base, size_t BP,
                                int32_t* __restrict__ rc, int32_t* __restrict__ ex, int32_t* __restrict__ snk,
                                int32_t* __restrict__ dist, uint8_t* __restrict__ rmask, PushTileLds<TH>& S, int lane,
                                bool prof, long long (&pv)[4]) {
@@ -257,6 +258,7 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, int
         if (i < HALO) sd[i] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? hv[k] : DINF;
     }
     if (lane < 32) S.mask[lane] = 0u;
+    for (int i = lane; i < 32 * TH / 4; i += 64) reinterpret_cast<uint32_t*>(S.streak)[i] = 0u;
     mf_wave_sync();
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
@@ -330,6 +332,7 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, int
                             hmin = ok ? hq[dir] : hmin; best = ok ? dir : best; rb = ok ? r[dir] : rb;
                         }
                         if (best >= 0 && dp > hmin) {
+                            S.streak[slot] = 0;
                             if (best == 8) {
                                 const int dl = min(e, sk);
                                 S.sk[slot] = sk - dl;                  // only the holder of the pixel's excess touches its sink link
@@ -358,7 +361,14 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, int
                             const int nd = (best >= 0 && hmin < DINF) ? hmin + 1 : DINF;
                             S.d[ly + 1][plx + 1] = nd;
                             atomicAdd(&S.ex[slot], e);                 // give it back; with the new label the next step can push
-                            if (nd >= d.P) slot = -1;
+                            // A pixel that only climbs — `park` relabels in a row without a push — is left alone for the rest of
+                            // this visit and does not keep the tile on the queue; the next global relabel gives it an exact label
+                            // (or none) and the active scan finds it again.  Off by default (GGC_MF_ASYNC_PARK, 255): measured
+                            // without effect at 2-6 — trapped excess does not climb in place, it is pushed back and forth between
+                            // the pixels of its pocket, every push resetting the streak.
+                            const int sr = S.streak[slot] + 1;
+                            S.streak[slot] = (unsigned char)min(sr, 255);
+                            if (nd >= d.P || sr >= park) slot = -1;
                         }
                     }
                 }
@@ -400,7 +410,7 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, int
         }
         if (sk1 != sk0[j]) atomicExch(&snk[p], sk1);
         // the label: compare with the halo copy's origin is not kept, so write when the pixel was relabelled (d only rises here)
-        left |= (e1 > 0 && d1 < d.P) ? 1 : 0;
+        left |= (e1 > 0 && d1 < d.P && S.streak[slot] < park) ? 1 : 0;
     }
     // labels: a pixel's label is written when it differs from what memory held at load time
 #pragma unroll
@@ -417,7 +427,7 @@ __device__ int push_tile_visit(const GcDims& d, int tyi, int txi, int inner, int
 }
 
 template <int TH>
-__global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt_y, int pt_y, int inner, int chase, int gen_max, int follow, int32_t* __restrict__ dirty, int32_t* __restrict__ rc,
+__global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt_y, int pt_y, int inner, int chase, int park, int gen_max, int follow, int32_t* __restrict__ dirty, int32_t* __restrict__ rc,
                                                       int32_t* __restrict__ ex, int32_t* __restrict__ snk, int32_t* __restrict__ dist,
                                                       uint8_t* __restrict__ rmask, int32_t* __restrict__ st, unsigned long long* __restrict__ ring,
                                                       int32_t* __restrict__ q, int cap, int32_t* __restrict__ err_flag,
@@ -452,7 +462,7 @@ __global__ void __launch_bounds__(64) k_mf_push_async(GcDims d, int bt_x, int bt
         const long long t_1 = prof ? wall_clock64() : 0;
         const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
         const int tyi = tr / bt_x, txi = tr % bt_x;
-        const int nbm = push_tile_visit<TH>(d, tyi, txi, inner, chase, (size_t)b * d.P, BP, rc, ex, snk, dist, rmask, S, lane, prof != nullptr, pv);
+        const int nbm = push_tile_visit<TH>(d, tyi, txi, inner, chase, park, (size_t)b * d.P, BP, rc, ex, snk, dist, rmask, S, lane, prof != nullptr, pv);
         drain();                                                           // the write-back is at memory
         const long long t_2 = prof ? wall_clock64() : 0;
         const bool left = (nbm >> 4) & 1;
@@ -532,18 +542,19 @@ int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTi
     const int bt_x = tl.pt_x, bt_y = cdiv(d.H, th), cap = bt_x * bt_y * d.B;
     gen_max = std::min(gen_max, 127);
     static const int follow = [] { const char* e = std::getenv("GGC_MF_ASYNC_FOLLOW"); return e ? std::atoi(e) : 1; }();
+    static const int park = [] { const char* e = std::getenv("GGC_MF_ASYNC_PARK"); return e ? std::max(1, std::atoi(e)) : 255; }();
     static const int chase = [] { const char* e = std::getenv("GGC_MF_ASYNC_CHASE"); return e ? std::max(1, std::atoi(e)) : 1; }();   // > 1 measured slower: most sparse-round excess is trapped and only climbs labels faster
     mf_zero3(st, reinterpret_cast<int32_t*>(ring), (size_t)cap * 2, q, AQ_WORDS, state, (size_t)cap);
     hipLaunchKernelGGL(k_aq_fill_big, dim3(cdiv(n_list_max, 256)), dim3(256), 0, st, count, list, tl.pt_x, tl.pt_y, th, bt_x, bt_y, state, ring, q,
                        gen_max);
     if (th == 32)
-        hipLaunchKernelGGL(k_mf_push_async<32>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, chase, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<32>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, chase, park, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag, prof);
     else if (th == 8)
-        hipLaunchKernelGGL(k_mf_push_async<8>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, chase, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<8>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, chase, park, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag, prof);
     else
-        hipLaunchKernelGGL(k_mf_push_async<16>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, chase, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
+        hipLaunchKernelGGL(k_mf_push_async<16>, dim3(waves), dim3(64), 0, st, d, bt_x, bt_y, tl.pt_y, inner, chase, park, gen_max, follow, dirty, rc, ex, snk, dist, rmask, state, ring, q, cap,
                            err_flag, prof);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
