@@ -2,11 +2,34 @@
 #include "ggc_internal.h"
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <mutex>
 
 static thread_local std::string g_create_err;   // ggc_last_error(NULL) reports the calling thread's failed ggc_ctx_create
 
 namespace ggc {
+
+const Knobs& knobs() {
+    static const Knobs k = [] {
+        auto num = [](const char* name, int dflt, int lo) { const char* e = std::getenv(name); return e ? std::max(lo, std::atoi(e)) : dflt; };
+        Knobs k;
+        k.mf_trace = std::getenv("GGC_MF_TRACE") != nullptr;
+        k.mf_warm = num("GGC_MF_WARM", 1, 0);
+        k.mf_async = num("GGC_MF_ASYNC", 1, 0);
+        k.mf_async_push_active = num("GGC_MF_ASYNC_PUSH_ACTIVE", 10000, 0);
+        k.mf_async_tile = num("GGC_MF_ASYNC_TILE", 8, 8);
+        k.mf_async_hops = num("GGC_MF_ASYNC_HOPS", 24, 1);
+        k.mf_async_sweeps = num("GGC_MF_ASYNC_SWEEPS", 12, 1);
+        k.mf_dense_launches = num("GGC_MF_DENSE_LAUNCHES", 12, 1);
+        k.mf_dense_launches0 = num("GGC_MF_DENSE_LAUNCHES0", 8, 1);
+        k.mf_dense_sweeps = num("GGC_MF_DENSE_SWEEPS", 8, 1);
+        k.mf_relax_dense = num("GGC_MF_RELAX_DENSE", 2, 1);
+        k.agg_direct = num("GGC_AGG_DIRECT", 0, 0);
+        k.slic_seq_connectivity = num("GGC_SLIC_SEQ_CONNECTIVITY", 0, 0);
+        return k;
+    }();
+    return k;
+}
 
 int set_err(ggc_ctx* ctx, int code, const char* fmt, ...) {
     char buf[1024];

@@ -27,14 +27,13 @@ __host__ __device__ __forceinline__ size_t rc_idx(int dir, size_t i) { return i 
 // Maximum preflow + canonical labels for every image with state[b] == 0.
 //   rc   [B][P][8] residual capacities (in/out), rc_idx(dir, pixel)     ex, snk [B][P] excess / residual sink capacity (in/out)
 //   dist [B][P] out: distance to the sink in the final residual graph, >= DINF when unreachable (=> foreground)
-//   rmask [B][P] scratch, lists [2B] scratch, flags [2B+1] scratch
-// handoff_active > 0: once the batch is down to that many active pixels the open images are finished by maxflow_image()
-// (err_flag: device word that receives a non-zero code if that launch does not converge).
+//   rmask [B][P] arc masks of rc (bit dir = residual arc towards dir); masks_exact: every byte is current (cold start) —
+//   otherwise the tiles marked dirty by the previous solve keep their mark.  lists [2B], flags [2B+16] scratch;
+//   err_flag: device word that receives a non-zero code if an asynchronous launch gives up.
 int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
-            int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists, int32_t* flags, int32_t* err_flag, int handoff_active);
+            int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists, int32_t* flags, int32_t* err_flag, bool masks_exact);
 
-// Tile geometry shared by the two drivers of the algorithm (ggc_maxflow.hip: one launch per sweep over work lists
-// of tiles of the whole batch; ggc_maxflow_image.hip: one resident workgroup per image, rounds decided on the device).
+// Tile geometry of the max-flow kernels (ggc_maxflow.hip: launches over work lists; ggc_maxflow_async.hip: one launch per sparse phase)
 constexpr int MF_RT = 32;                          // relabel tile side
 constexpr int MF_PT_W = 32, MF_PT_H = 8;           // push tile
 struct MfTiles { int rt_x, rt_y, pt_x, pt_y; };    // tiles per image
@@ -55,18 +54,5 @@ int maxflow_relax_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfT
 int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTiles& tl, int th, int inner, int gen_max, int32_t* rc,
                        int32_t* ex, int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* dirty, const int32_t* count, const int32_t* list, int n_list_max, int32_t* state,
                        unsigned long long* ring, int32_t* q, int waves, int32_t* err_flag, long long* prof = nullptr);
-
-// One workgroup per image runs the whole max-flow (every round of global relabel + push sweeps) in a single launch.
-// Returns GGC_E_UNSUPPORTED without touching anything when the image has more tiles than the kernel's LDS bitmap holds.
-bool maxflow_image_fits(const GcDims& d);
-// push_passes > 0: ONE push phase only (that many passes of push_inner sweeps per tile visit) on the labels in dist, which
-// must be this round's exact distances; the caller relabels afterwards.  0: the whole max-flow.
-int maxflow_image(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
-                  int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* err_flag, int push_passes = 0, int push_inner = 0);
-// One launch per max-flow, a pool of resident waves over per-image task lists (ggc_maxflow_pool.hip).  rmask must hold the
-// arc masks of rc on entry (k_build_graph writes them).
-bool maxflow_pool_fits(const GcDims& d);
-int maxflow_pool(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
-                 int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* err_flag);
 
 } // namespace ggc

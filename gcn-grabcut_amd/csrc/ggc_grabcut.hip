@@ -499,6 +499,10 @@ __global__ void __launch_bounds__(256) k_build_graph(GcDims d, const uint8_t* __
     const size_t i = (size_t)b * d.P + p;
     const int y = p / d.W, x = p % d.W;
     const uint8_t m = mask[i];
+    // Warm start, definite pixel: its t-link (+-lambda) is what it was, so the new balance tw + inflow equals the old one —
+    // and a finished solve leaves no pixel with both excess and sink capacity, so excess, sink link, capacities and arc
+    // mask are already what this kernel would write (59 % of the bench's pixels are definite background).
+    if (warm && (m == GGC_BGD || m == GGC_FGD)) return;
     double dv;
     if (m == GGC_BGD) dv = -LAMBDA;
     else if (m == GGC_FGD) dv = LAMBDA;
@@ -633,33 +637,17 @@ extern "C" int ggc_grabcut(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
         hipLaunchKernelGGL(k_nweights, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, image, bsum, nw);
         GGC_LAUNCH_CHECK(ctx);
         for (int it = 0; it < n_iter; ++it) {
+            const bool warm = knobs().mf_warm && it > 0;
             {
                 ProfScope prof(ctx, st, "grabcut_gmm");
                 hipLaunchKernelGGL((k_gmm_accum<1>), dim3(cdiv(d.P, 256 * BIN_PX), B), dim3(256), 0, st, d, image, mask, state, gmm, comp, acc);
                 hipLaunchKernelGGL(k_gmm_learn, dim3(cdiv(B * 2, 64)), dim3(64), 0, st, B, state, acc, gmm);
-                static const bool warm_ok = [] { const char* e = std::getenv("GGC_MF_WARM"); return !(e && e[0] == '0'); }();
-                hipLaunchKernelGGL(k_build_graph, dim3(cdiv(d.P, 256), B), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk, rmask,
-                                   (warm_ok && it > 0) ? 1 : 0);
+                hipLaunchKernelGGL(k_build_graph, dim3(cdiv(d.P, 256), B), dim3(256), 0, st, d, image, mask, state, gmm, nw, rc, ex, snk, rmask, warm ? 1 : 0);
             }
             GGC_LAUNCH_CHECK(ctx);
-            // GGC_MF_DRIVER selects who drives the rounds of the max-flow (same kernels' worth of algorithm, same canonical cut):
-            //   host (default)  work lists over the whole batch, one launch per sweep, list sizes read back by the host
-            //   hybrid          host for the rounds that move most of the flow, then one resident workgroup per open image
-            //   image           one resident workgroup per image from the start, rounds decided on the device (1 launch)
-            //   pool            task pool of resident waves with per-XCD image ownership (1 launch)
-            // Measured on MI355X ("max-flow drivers"): host is the fastest at every batch size tried, so it stays
-            // the default; the device-driven ones are kept, tested, as measured alternatives.  Images beyond the per-image
-            // kernels' tile bitmap always take the host driver.
-            static const int driver = [] {
-                const char* e = std::getenv("GGC_MF_DRIVER");
-                return !e ? 2 : (e[0] == 'i' ? 1 : (e[0] == 'p' ? 3 : (e[0] == 'h' && e[1] == 'y' ? 0 : 2)));
-            }();
-            static const int handoff = [] { const char* e = std::getenv("GGC_MF_HANDOFF_PER_IMAGE"); return e ? std::atoi(e) : 16; }();
-            int rcode;
-            if (driver == 3 && maxflow_pool_fits(d)) rcode = maxflow_pool(ctx, st, d, state, rc, ex, snk, dist, rmask, err + 1);
-            else if (driver == 1 && maxflow_image_fits(d)) rcode = maxflow_image(ctx, st, d, state, rc, ex, snk, dist, rmask, err + 1);
-            else rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 6 * B + 16, mf_flags, err + 1,
-                                 driver == 0 ? handoff * B : 0);
+            // who drives the rounds of the max-flow was measured in round 2 ("max-flow drivers"): launches over
+            // work lists for the dense phases, one asynchronous launch for each sparse phase (ggc_maxflow_async.hip)
+            const int rcode = maxflow(ctx, st, d, state, rc, ex, snk, dist, rmask, small + 6 * B + 16, mf_flags, err + 1, !warm);
             if (rcode) return rcode;
             hipLaunchKernelGGL(k_gc_relabel, dim3(cdiv(BP, 256)), dim3(256), 0, st, d, state, dist, mask);
             GGC_LAUNCH_CHECK(ctx);

@@ -86,6 +86,23 @@ struct ggc_ctx {
 
 namespace ggc {
 
+// Every environment switch of the library, read ONCE per process by knobs() (ggc_context.hip); include/ggc.h documents them.
+struct Knobs {
+    int mf_trace;               // GGC_MF_TRACE: per-round max-flow diagnostics on stderr (blocking; tools/mf_trace.py)
+    int mf_warm;                // GGC_MF_WARM (1): keep the n-link flow across GrabCut iterations
+    int mf_async;               // GGC_MF_ASYNC (1): sparse max-flow phases as one asynchronous launch each; 0 = host-driven work lists only
+    int mf_async_push_active;   // GGC_MF_ASYNC_PUSH_ACTIVE (10000): push rounds with at most this many active pixels run asynchronously
+    int mf_async_tile;          // GGC_MF_ASYNC_TILE (8): rows of the asynchronous push tile, 8 | 16 | 32
+    int mf_async_hops;          // GGC_MF_ASYNC_HOPS (24): longest chain of tile visits in an asynchronous push launch
+    int mf_async_sweeps;        // GGC_MF_ASYNC_SWEEPS (12): sweeps per asynchronous push visit
+    int mf_dense_launches0, mf_dense_launches;   // GGC_MF_DENSE_LAUNCHES0 (8) / GGC_MF_DENSE_LAUNCHES (12): push launches of the first / a later dense round
+    int mf_dense_sweeps;        // GGC_MF_DENSE_SWEEPS (8): sweeps per dense push visit
+    int mf_relax_dense;         // GGC_MF_RELAX_DENSE (2): work-list launches of a relabel before the asynchronous one takes over
+    int agg_direct;             // GGC_AGG_DIRECT (0): 1 = GCNConv gather straight from L2 (k_aggregate) instead of the graph-resident kernel
+    int slic_seq_connectivity;  // GGC_SLIC_SEQ_CONNECTIVITY (0): 1 = literal one-thread-per-image raster replay of skimage's connectivity pass
+};
+const Knobs& knobs();
+
 int set_err(ggc_ctx* ctx, int code, const char* fmt, ...);
 // small synchronous device -> host read through the context's pinned staging buffer (stream sync)
 int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std::vector<int32_t>& host);

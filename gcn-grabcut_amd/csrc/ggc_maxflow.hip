@@ -33,18 +33,11 @@
 
 namespace ggc {
 
-#ifndef GGC_MF_HOST_RT
-#define GGC_MF_HOST_RT MF_RT
-#endif
-constexpr int RT = GGC_MF_HOST_RT;    // relabel tile side of this driver (experiments: -DGGC_MF_HOST_RT=64)
-constexpr int RT_ROWS = 256 / RT;      // tile rows covered by one pass of the 256 threads
-constexpr int RT_NJ = RT * RT / 256;   // pixels per thread
+constexpr int RT = MF_RT;              // relabel tile side
 constexpr int PT_W = MF_PT_W, PT_H = MF_PT_H;   // push tile (32x16 measured 6 % slower end to end)
 constexpr int PT_N = PT_W * PT_H;      // threads of a push block, one pixel each
-// blocks per work-list launch (relabel, push): a block walks several tiles of the list
-static int grid_env(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::max(64, std::atoi(e)) : dflt; }
-static const int LIST_GRID = grid_env("GGC_MF_LIST_GRID", 1024);
-static const int RELAX_GRID = grid_env("GGC_MF_RELAX_GRID", 2 * LIST_GRID), PUSH_GRID = grid_env("GGC_MF_PUSH_GRID", LIST_GRID);
+// blocks per work-list launch and 64 open images: a block walks several tiles of the list (measured best, tools/mf_knobs.sh)
+constexpr int PUSH_GRID = 1024, RELAX_GRID = 1024, ASYNC_GRID = 128;
 
 __device__ __forceinline__ int ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -89,43 +82,10 @@ __device__ __forceinline__ void flush_tiles(OutList& L, int32_t* __restrict__ li
     for (int i = threadIdx.x; i < n; i += blockDim.x) list[L.base + i] = L.buf[i];
 }
 
-// start of a global relabel: d = 1 next to the sink, infinity elsewhere.  rmask bit dir = residual arc p -> nb(dir): written by
-// k_build_graph and kept current by every push visit for the pixels it owns (the arcs that LEAVE a 32x8 push tile can be
-// re-opened by the neighbouring tile's pushes, so the relabel kernels read those from the capacities themselves), which
-// spares this pass the 8 capacity planes (41 -> 8 bytes per pixel; 26 GB per 256-image step before).  REBUILD: the masks
-// are recomputed here, for the block-per-tile relabel kernel that takes them as they are.
-template <bool REBUILD>
-__global__ void __launch_bounds__(256) k_mf_dinit(GcDims d, const int32_t* __restrict__ open_list, const int32_t* __restrict__ snk,
-                                                  const int32_t* __restrict__ rc, int32_t* __restrict__ dist,
-                                                  uint8_t* __restrict__ rmask) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t BP = (size_t)d.B * d.P;
-    if (p >= d.P) return;
-    const size_t i = (size_t)open_list[blockIdx.y] * d.P + p;
-    dist[i] = snk[i] > 0 ? 1 : DINF;
-    if (REBUILD) {
-        int m = 0;
-#pragma unroll
-        for (int dir = 0; dir < 8; ++dir) m |= (rc[rc_idx(dir, i)] > 0) ? (1 << dir) : 0;
-        rmask[i] = (uint8_t)m;
-    }
-}
-
-// every relabel tile of every open image starts on the frontier
-__global__ void k_mf_list_all(int n_open, const int32_t* __restrict__ open_list, int tiles_per_image,
-                              int32_t* __restrict__ list, int32_t* __restrict__ flag, int32_t* __restrict__ counters) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { counters[0] = n_open * tiles_per_image; counters[1] = 0; counters[2] = 0; }
-    if (i >= n_open * tiles_per_image) return;
-    const int tile = open_list[i / tiles_per_image] * tiles_per_image + i % tiles_per_image;
-    list[i] = tile;
-    flag[tile] = 1;
-}
-
 // Start of a global relabel by TILES (the wave-per-tile relabel kernels): a wave writes the starting labels of one 32x32
 // tile (1 next to the sink, infinity elsewhere) and puts the tile on the first work list only if it holds a pixel WITHOUT a
 // sink link — a tile whose pixels all touch the sink (59 % of the bench's pixels are definite background) is final at
-// label 1 and never needs a visit.  Replaces k_mf_dinit<false> + k_mf_list_all.
+// label 1 and never needs a visit.  (Folding this pass into the first relabel launch was measured in round 3: the heavy kernel then visits every tile, 99 us against 18 + 70.)
 __global__ void __launch_bounds__(256) k_mf_rinit(GcDims d, MfTiles tl, const int32_t* __restrict__ open_list,
                                                   const int32_t* __restrict__ snk, int32_t* __restrict__ dist,
                                                   int32_t* __restrict__ list, int32_t* __restrict__ flag, int32_t* __restrict__ count) {
@@ -162,115 +122,7 @@ __global__ void __launch_bounds__(256) k_mf_rinit(GcDims d, MfTiles tl, const in
     flush_tiles(outl, list, count);
 }
 
-// Global relabel over a work list of 32x32 tiles.
-__global__ void __launch_bounds__(256) k_mf_relax_list(GcDims d, MfTiles tl, int phase, const uint8_t* __restrict__ rmask,
-                                                       int32_t* __restrict__ dist, int32_t* __restrict__ counters,
-                                                       const int32_t* __restrict__ list_in, int32_t* __restrict__ list_out,
-                                                       int32_t* __restrict__ flag_in, int32_t* __restrict__ flag_out) {
-    __shared__ int sd[RT + 2][RT + 2];
-    __shared__ int s_nb;
-    const int tid = threadIdx.x;
-    const int n_in = counters[phase % 3];
-    int32_t* n_out = counters + (phase + 1) % 3;
-    if (blockIdx.x == 0 && tid == 0) counters[(phase + 2) % 3] = 0;       // the list after next starts empty
-    const int tiles_per_image = tl.rt_x * tl.rt_y;
-    const int lx = tid % RT;
-    // the block's next tile is loaded while the current one is relaxed (a stale halo only delays: the neighbour that
-    // lowers it afterwards puts this tile on the next list)
-    constexpr int N_HALO = (RT + 2) * (RT + 2), HALO_IT = (N_HALO + 255) / 256;
-    struct TileRegs { int hv[HALO_IT], msk[RT_NJ]; };
-    auto load_tile = [&](int tile, TileRegs& R) {
-        const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
-        const int ty0 = (tr / tl.rt_x) * RT, tx0 = (tr % tl.rt_x) * RT;
-        const size_t base = (size_t)b * d.P;
-#pragma unroll
-        for (int k = 0; k < HALO_IT; ++k) {
-            const int i = tid + k * 256;
-            const int gy = ty0 + i / (RT + 2) - 1, gx = tx0 + i % (RT + 2) - 1;
-            R.hv[k] = (i < N_HALO && gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? dist[base + (size_t)gy * d.W + gx] : DINF;
-        }
-#pragma unroll
-        for (int j = 0; j < RT_NJ; ++j) {
-            const int gy = ty0 + (tid / RT) + RT_ROWS * j, gx = tx0 + lx;
-            R.msk[j] = (gx < d.W && gy < d.H) ? rmask[base + (size_t)gy * d.W + gx] : 0;
-        }
-    };
-    const int G = gridDim.x;
-    int t = blockIdx.x;
-    if (t >= n_in) return;
-    int tile_next = list_in[t];
-    int tile_next2 = t + G < n_in ? list_in[t + G] : 0;
-    TileRegs N;
-    load_tile(tile_next, N);
-    for (; t < n_in; t += G) {
-        const int tile = tile_next;
-        const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
-        const int tyi = tr / tl.rt_x, txi = tr % tl.rt_x;
-        const int tx0 = txi * RT, ty0 = tyi * RT;
-        const size_t base = (size_t)b * d.P;
-        __syncthreads();                                                   // previous tile's LDS use is over
-        if (tid == 0) s_nb = 0;
-        int msk[RT_NJ], old[RT_NJ];
-#pragma unroll
-        for (int j = 0; j < RT_NJ; ++j) msk[j] = N.msk[j];
-#pragma unroll
-        for (int k = 0; k < HALO_IT; ++k) {
-            const int i = tid + k * 256;
-            if (i < N_HALO) sd[i / (RT + 2)][i % (RT + 2)] = N.hv[k];
-        }
-        if (t + G < n_in) {                                                // block-uniform
-            tile_next = tile_next2;
-            tile_next2 = t + 2 * G < n_in ? list_in[t + 2 * G] : 0;
-            load_tile(tile_next, N);
-        }
-        __syncthreads();
-        if (tid == 0) flag_in[tile] = 0;                                   // consumed
-#pragma unroll
-        for (int j = 0; j < RT_NJ; ++j) old[j] = sd[(tid / RT) + RT_ROWS * j + 1][lx + 1];
-        bool settled = false;
-        for (int it = 0; it < 4 * RT; ++it) {
-            int ch = 0;
-#pragma unroll
-            for (int j = 0; j < RT_NJ; ++j) {
-                if (!msk[j]) continue;
-                const int ly = (tid / RT) + RT_ROWS * j + 1, cx = lx + 1;
-                int nd = DINF;
-                if (msk[j] & 1) nd = min(nd, sd[ly][cx - 1]);
-                if (msk[j] & 2) nd = min(nd, sd[ly][cx + 1]);
-                if (msk[j] & 4) nd = min(nd, sd[ly - 1][cx]);
-                if (msk[j] & 8) nd = min(nd, sd[ly + 1][cx]);
-                if (msk[j] & 16) nd = min(nd, sd[ly - 1][cx - 1]);
-                if (msk[j] & 32) nd = min(nd, sd[ly + 1][cx + 1]);
-                if (msk[j] & 64) nd = min(nd, sd[ly - 1][cx + 1]);
-                if (msk[j] & 128) nd = min(nd, sd[ly + 1][cx - 1]);
-                if (nd < DINF && nd + 1 < sd[ly][cx]) { sd[ly][cx] = nd + 1; ch = 1; }
-            }
-            if (!__syncthreads_or(ch)) { settled = true; break; }
-        }
-        // A neighbour tile only has to go again when a pixel of its halo changed, i.e. a pixel on our border towards
-        // it (3 of 4 tile visits used to find nothing new); this tile itself only when the sweep cap cut it short.
-        int nbm = settled ? 0 : 1 << 4;                                    // bit (dy + 1) * 3 + (dx + 1)
-#pragma unroll
-        for (int j = 0; j < RT_NJ; ++j) {
-            const int ly = (tid / RT) + RT_ROWS * j;
-            const int v = sd[ly + 1][lx + 1];
-            if (v != old[j]) {
-                dist[base + (size_t)(ty0 + ly) * d.W + tx0 + lx] = v;
-                const int L = lx == 0, R = lx == RT - 1, U = ly == 0, D = ly == RT - 1;
-                nbm |= (U & L) | U << 1 | (U & R) << 2 | L << 3 | R << 5 | (D & L) << 6 | D << 7 | (D & R) << 8;
-            }
-        }
-        if (nbm) atomicOr(&s_nb, nbm);
-        __syncthreads();
-        if (tid < 9 && (s_nb >> tid) & 1) {
-            const int ty = tyi + tid / 3 - 1, tx = txi + tid % 3 - 1;
-            if (ty >= 0 && ty < tl.rt_y && tx >= 0 && tx < tl.rt_x)
-                push_tile(b * tiles_per_image + ty * tl.rt_x + tx, flag_out, list_out, n_out);
-        }
-    }
-}
-
-// The same relabel with a WAVE per tile (4 tiles per block, no block barrier): the labels are relaxed by alternating
+// Global relabel over a work list of 32x32 tiles, a WAVE per tile (4 tiles per block, no block barrier): the labels are relaxed by alternating
 // vertical and horizontal in-register sweeps (ggc_mf_sweep.h), which carry a front across the tile in a handful of
 // sweeps where the neighbour-at-a-time iteration above needs one per pixel of the way.  32x32 tiles only.
 struct RelaxWaveLds { int d[MF_RT + 2][MF_RT + 2]; uint32_t m[MF_RT][MF_RT / 4]; };
@@ -582,214 +434,6 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
     flush_tiles(outl, list_out, n_out);
 }
 
-// The same push-relabel sweeps with a WAVE per tile (4 tiles per block, no block barrier).  The block-per-tile kernel above
-// is bound by instruction issue, not by memory or latency: every one of a tile's 4 waves runs the ~120-instruction active
-// path in every sweep as soon as one of its 64 pixels is active, and only ~12 % of the pixels of a visited tile are — a
-// dense launch moved its ~15 000 tiles at ~110 tiles per microsecond whatever the grid, the occupancy or the list-counter
-// traffic (measured).  Here a sweep first compacts the tile's active pixels into an LDS list (ballot + mbcnt) and hands ONE
-// active pixel to each lane: the active path runs once per 64 active pixels instead of once per wave of the tile, about a
-// third of the instructions per visit.  Loads, write-back (interior plain, ring as atomic deltas), arc masks and work lists
-// are those of k_mf_pr_list; 4 pixels per lane.
-struct PushWaveLds { int ex[PT_N]; int sk[PT_N]; int d[PT_H + 2][PT_W + 2]; int rc[8][PT_N]; unsigned short act[PT_N]; };
-
-template <bool PROF>
-__global__ void __launch_bounds__(256) k_mf_pr_wave(GcDims d, MfTiles tl, int phase, int inner, long long* __restrict__ prof,
-                                                    int32_t* __restrict__ rc, int32_t* __restrict__ ex,
-                                                    int32_t* __restrict__ snk, int32_t* __restrict__ dist, uint8_t* __restrict__ rmask,
-                                                    int32_t* __restrict__ dirty, int32_t* __restrict__ counters, const int32_t* __restrict__ list_in,
-                                                    int32_t* __restrict__ list_out, int32_t* __restrict__ flag_in,
-                                                    int32_t* __restrict__ flag_out) {
-    static_assert(PT_W == 32 && PT_N % 64 == 0, "wave-per-tile push kernel: 32-pixel tile rows");
-    constexpr int PX = PT_N / 64, N_HALO = (PT_H + 2) * (PT_W + 2), HALO_IT = (N_HALO + 63) / 64;
-    __shared__ PushWaveLds lds[4];
-    __shared__ OutList outl;
-    if (threadIdx.x == 0) outl.n = 0;
-    __syncthreads();
-    const int wv = threadIdx.x >> 6;
-    PushWaveLds& S = lds[wv];
-    const int n_in = counters[phase % 3];
-    int32_t* n_out = counters + (phase + 1) % 3;
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[(phase + 2) % 3] = 0;
-    const int tiles_per_image = tl.pt_x * tl.pt_y;
-    const size_t BP = (size_t)d.B * d.P;
-    const int G = gridDim.x * 4;
-    int* sd = &S.d[0][0];
-    long long pa = 0, pb = 0, pc = 0, pn = 0, psw = 0, pac = 0;
-    int tile_nx = blockIdx.x * 4 + wv < n_in ? list_in[blockIdx.x * 4 + wv] : 0;   // (list entry one visit ahead, see k_mf_relax_wave)
-    for (int t = blockIdx.x * 4 + wv; t < n_in; t += G) {
-        int lane = threadIdx.x & 63;
-        asm volatile("" : "+v"(lane));                                     // keeps the lane arithmetic inside the loop (no hoist + spill)
-        const long long t_a = PROF ? wall_clock64() : 0;
-        const int tile = __builtin_amdgcn_readfirstlane(tile_nx);
-        tile_nx = t + G < n_in ? list_in[t + G] : 0;
-        const int b = tile / tiles_per_image, tr = tile % tiles_per_image;
-        const int tyi = tr / tl.pt_x, txi = tr % tl.pt_x;
-        const size_t base = (size_t)b * d.P;
-        const int lx = lane & 31, r0 = lane >> 5;
-        const int x = txi * PT_W + lx;
-        int e0[PX], sk0[PX], d0[PX], r0v[PX][8], pp[PX];
-        bool inb[PX];
-        // all loads of the visit are issued unconditionally from clamped addresses, then masked
-#pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            const int y = tyi * PT_H + r0 + 2 * j;
-            inb[j] = x < d.W && y < d.H;
-            pp[j] = y * d.W + x;
-            const int pc = min(y, d.H - 1) * d.W + min(x, d.W - 1);
-            e0[j] = ex[base + pc];
-            sk0[j] = snk[base + pc];
-#pragma unroll
-            for (int dir = 0; dir < 8; ++dir) r0v[j][dir] = rc[rc_idx(dir, base + pc)];
-        }
-        int hv[HALO_IT];
-#pragma unroll
-        for (int k = 0; k < HALO_IT; ++k) {
-            const int i = min(lane + k * 64, N_HALO - 1);
-            const int gy = tyi * PT_H + i / (PT_W + 2) - 1, gx = txi * PT_W + i % (PT_W + 2) - 1;
-            hv[k] = dist[base + (size_t)min(max(gy, 0), d.H - 1) * d.W + min(max(gx, 0), d.W - 1)];
-        }
-        if (lane == 0) flag_in[tile] = 0;                                  // consumed
-#pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            const int slot = lane + 64 * j;
-            if (!inb[j]) { e0[j] = 0; sk0[j] = 0; }
-            S.ex[slot] = e0[j];
-            S.sk[slot] = sk0[j];
-#pragma unroll
-            for (int dir = 0; dir < 8; ++dir) {
-                if (!inb[j]) r0v[j][dir] = 0;
-                S.rc[dir][slot] = r0v[j][dir];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < HALO_IT; ++k) {
-            const int i = lane + k * 64;
-            const int gy = tyi * PT_H + i / (PT_W + 2) - 1, gx = txi * PT_W + i % (PT_W + 2) - 1;
-            if (i < N_HALO) sd[i] = (gx >= 0 && gx < d.W && gy >= 0 && gy < d.H) ? hv[k] : DINF;
-        }
-        mf_wave_sync();
-#pragma unroll
-        for (int j = 0; j < PX; ++j) d0[j] = S.d[r0 + 2 * j + 1][lx + 1];
-        const long long t_b = PROF ? wall_clock64() : 0;
-        int n_sw = 0, n_ac = 0, nbm = 0;                                   // nbm bit (dy + 1) * 3 + (dx + 1): neighbour tile received excess
-        for (int it = 0; it < inner; ++it) {
-            // ---- compact the active pixels of the tile (slot order)
-            int n_act = 0;
-#pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                const int slot = lane + 64 * j;
-                const bool a = inb[j] && S.ex[slot] > 0 && S.d[r0 + 2 * j + 1][lx + 1] < d.P;
-                const unsigned long long m = __ballot(a);
-                if (a) S.act[n_act + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)slot;
-                n_act += __popcll(m);
-            }
-            mf_wave_sync();
-            if (n_act == 0) break;
-            if (PROF) { ++n_sw; n_ac += n_act; }
-            // ---- one active pixel per lane
-            for (int k0 = 0; k0 < n_act; k0 += 64) {
-                const int k = k0 + lane;
-                if (k < n_act) {
-                    const int slot = S.act[k], ly = slot >> 5, plx = slot & 31;
-                    const int e = __hip_atomic_load(&S.ex[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const int dp = S.d[ly + 1][plx + 1];
-                    const int sk = S.sk[slot];
-                    int r[8], hq[8];
-#pragma unroll
-                    for (int dir = 0; dir < 8; ++dir) {
-                        r[dir] = __hip_atomic_load(&S.rc[dir][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        hq[dir] = S.d[ly + 1 + dir_dy(dir)][plx + 1 + dir_dx(dir)];
-                    }
-                    int hmin = sk > 0 ? 0 : DINF, best = sk > 0 ? 8 : -1, rb = 0;
-#pragma unroll
-                    for (int dir = 0; dir < 8; ++dir) {
-                        const bool ok = r[dir] > 0 && hq[dir] < hmin;
-                        hmin = ok ? hq[dir] : hmin; best = ok ? dir : best; rb = ok ? r[dir] : rb;
-                    }
-                    if (best >= 0 && dp > hmin) {
-                        if (best == 8) {
-                            const int dl = min(e, sk);
-                            S.sk[slot] = sk - dl;                          // only this lane touches the pixel's sink link
-                            atomicSub(&S.ex[slot], dl);
-                        } else {
-                            const int dl = min(e, rb);
-                            atomicSub(&S.rc[best][slot], dl);
-                            atomicSub(&S.ex[slot], dl);
-                            const int qlx = plx + dir_dx(best), qly = ly + dir_dy(best);
-                            if (qlx >= 0 && qlx < PT_W && qly >= 0 && qly < PT_H) {
-                                const int qt = qly * PT_W + qlx;
-                                atomicAdd(&S.rc[best ^ 1][qt], dl);
-                                atomicAdd(&S.ex[qt], dl);
-                            } else {                                        // across the tile edge: straight to global memory
-                                const int gy = tyi * PT_H + qly, gx = txi * PT_W + qlx;
-                                const size_t qg = base + (size_t)gy * d.W + gx;
-                                atomicAdd(&rc[rc_idx((best ^ 1), qg)], dl);
-                                atomicAdd(&ex[qg], dl);
-                                // the neighbour tile is told AFTER the sweeps: its membership flag is a global load + exchange, and a
-                                // load inside the sweep loop waits for every atomic issued before it (measured: 10.8 us per sweep)
-                                const int tdy = qly < 0 ? -1 : (qly >= PT_H ? 1 : 0), tdx = qlx < 0 ? -1 : (qlx >= PT_W ? 1 : 0);
-                                nbm |= 1 << ((tdy + 1) * 3 + tdx + 1);
-                            }
-                        }
-                    } else {
-                        S.d[ly + 1][plx + 1] = (best >= 0 && hmin < DINF) ? hmin + 1 : DINF;
-                    }
-                }
-                mf_wave_sync();
-            }
-        }
-        const long long t_c = PROF ? wall_clock64() : 0;
-        int left = 0;
-#pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            // only the border ring can receive pushes from other tiles during this launch: the interior is a plain store
-            const int slot = lane + 64 * j, ly = r0 + 2 * j, p = pp[j];
-            const bool ring = lx == 0 || lx == PT_W - 1 || ly == 0 || ly == PT_H - 1;
-            const int e1 = S.ex[slot], sk1 = S.sk[slot], d1 = S.d[ly + 1][lx + 1];
-            int r1[8];
-#pragma unroll
-            for (int dir = 0; dir < 8; ++dir) r1[dir] = S.rc[dir][slot];
-            if (!inb[j]) continue;
-            if (e1 != e0[j]) { if (ring) atomicAdd(&ex[base + p], e1 - e0[j]); else ex[base + p] = e1; }
-            int m1 = 0, chg = 0;
-#pragma unroll
-            for (int dir = 0; dir < 8; ++dir) {
-                m1 |= (r1[dir] > 0) ? (1 << dir) : 0;
-                if (r1[dir] != r0v[j][dir]) {
-                    chg = 1;
-                    const bool out = (ly == 0 && dir_dy(dir) < 0) || (ly == PT_H - 1 && dir_dy(dir) > 0) ||
-                                     (lx == 0 && dir_dx(dir) < 0) || (lx == PT_W - 1 && dir_dx(dir) > 0);   // (see k_mf_pr_list)
-                    if (out) atomicAdd(&rc[rc_idx(dir, base + p)], r1[dir] - r0v[j][dir]);
-                    else rc[rc_idx(dir, base + p)] = r1[dir];
-                }
-            }
-            if (chg) rmask[base + p] = (uint8_t)m1;         // (arcs that leave the tile: the relabel reads the capacities, see k_mf_dinit)
-            if (sk1 != sk0[j]) snk[base + p] = sk1;
-            if (d1 != d0[j]) dist[base + p] = d1;
-            left |= (e1 > 0 && d1 < d.P) ? 1 : 0;
-        }
-        nbm = mf_wave_or(nbm | (left ? 1 << 4 : 0));                       // bit 4: this tile still has work
-        if (lane < 9 && (nbm >> lane) & 1) {
-            const int ty = tyi + lane / 3 - 1, tx = txi + lane % 3 - 1;    // (a push never leaves the image: those arcs have no capacity)
-            if (ty >= 0 && ty < tl.pt_y && tx >= 0 && tx < tl.pt_x) {
-                const int nbt = b * tiles_per_image + ty * tl.pt_x + tx;
-                if (lane != 4) dirty[nbt] = 1;                             // its border arcs may have been re-opened (ggc_mf_sweep.h)
-                push_tile_l(nbt, flag_out, outl, list_out, n_out);
-            }
-        }
-        mf_wave_sync();
-        if (PROF) {      // GGC_MF_TRACE: where a visit's time goes (wall_clock64 ticks at 100 MHz), kept in registers until the wave ends
-            pa += t_b - t_a; pb += t_c - t_b; pc += wall_clock64() - t_c; pn += 1; psw += n_sw; pac += n_ac;
-        }
-    }
-    if (PROF && (threadIdx.x & 63) == 0 && pn) {                           // one set of atomics per wave, spread over 64 slots
-        unsigned long long* q = reinterpret_cast<unsigned long long*>(prof) + (blockIdx.x & 63) * 8;
-        atomicAdd(&q[0], (unsigned long long)pa); atomicAdd(&q[1], (unsigned long long)pb); atomicAdd(&q[2], (unsigned long long)pc);
-        atomicAdd(&q[3], (unsigned long long)pn); atomicAdd(&q[4], (unsigned long long)psw); atomicAdd(&q[5], (unsigned long long)pac);
-    }
-    flush_tiles(outl, list_out, n_out);
-}
-
 // per image: number of pixels whose excess can still reach the sink; their push tiles form the round's first work list
 __global__ void __launch_bounds__(256) k_mf_active(GcDims d, MfTiles tl, const int32_t* __restrict__ open_list,
                                                    const int32_t* __restrict__ ex, const int32_t* __restrict__ dist,
@@ -821,16 +465,14 @@ __global__ void k_done_update(int n_cur, const int32_t* __restrict__ list_cur, c
     const int b = list_cur[i];
     if (active[b] != 0) { list_nxt[atomicAdd(n_open, 1)] = b; atomicAdd(n_open + 7, active[b]); }   // [7]: active pixels in total
 }
-// state array (0 = to do) of the still-open images, for the hand-over to the per-image driver
-__global__ void k_open_state(int B, int n_open, const int32_t* __restrict__ open_list, int32_t* __restrict__ st) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_open) st[open_list[i]] = 0;
-}
 __global__ void k_open_init(int B, const int32_t* __restrict__ state, int32_t* __restrict__ list, int32_t* __restrict__ n_open) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B && !state[b]) list[atomicAdd(n_open, 1)] = b;
 }
 
+// small synchronous device -> host read through the context's page-locked staging buffer.  (Round 3 measured the
+// alternative — a one-thread kernel publishing into host-coherent memory and the host spinning on a ticket instead of
+// hipStreamSynchronize: 58.4-58.8 vs 59.1-60.3 ms per GrabCut stage, 86.9 vs 87.1 ms per step: not worth four spinning cores.)
 int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std::vector<int32_t>& host) {
     host.resize(n);
     if (ctx->h_pinned && n <= ggc_ctx::H_PINNED_INTS) {
@@ -844,19 +486,11 @@ int read_i32(ggc_ctx* ctx, hipStream_t st, const int32_t* dev, int n, std::vecto
     return GGC_OK;
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e ? std::max(1, std::atoi(e)) : dflt;
-}
-static int env_int0(const char* name, int dflt) {       // zero allowed (switches)
-    const char* e = std::getenv(name);
-    return e ? std::max(0, std::atoi(e)) : dflt;
-}
-
 int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state, int32_t* rc, int32_t* ex,
             int32_t* snk, int32_t* dist, uint8_t* rmask, int32_t* lists /*[2B] open-image lists*/,
             int32_t* flags /*[B] active | [1] n_open | [3] relabel counters | [3] push counters | [1] active total*/,
-            int32_t* err_flag, int handoff_active) {
+            int32_t* err_flag, bool masks_exact) {
+    const Knobs& kn = knobs();
     const int B = d.B;
     int32_t* active = flags;
     int32_t* n_open = flags + B;
@@ -872,103 +506,69 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     int32_t *pt_list[2] = {pt, pt + n_pt}, *pt_flag[2] = {pt + 2 * n_pt, pt + 3 * n_pt};
     int32_t *list_cur = lists, *list_nxt = lists + B;
     // asynchronous single-launch drivers of the sparse phases (ggc_maxflow_async.hip): ring of the larger tile count, the
-    // queue words, one lock word per push tile
-    static const int async_relax = env_int0("GGC_MF_ASYNC_RELAX", 1), relax_dense = env_int0("GGC_MF_RELAX_DENSE", 2);
-    static const int async_push_active = env_int0("GGC_MF_ASYNC_PUSH_ACTIVE", 10000), async_gen = env_int("GGC_MF_ASYNC_GEN", 24);
-    static const int async_inner = env_int("GGC_MF_ASYNC_INNER", 12), async_grid = env_int("GGC_MF_ASYNC_GRID", 128);
-    static const int async_th = env_int("GGC_MF_ASYNC_TH", 8);
+    // queue words, one lock word per push tile; behind them the trace clocks and the dirty words
     const size_t ring_cap = std::max(n_rt, n_pt);
-    unsigned long long* ring = nullptr;
-    int32_t *aq = nullptr, *busy = nullptr;
-    {   // (allocated whatever the knobs say: the dirty flags and the trace clocks live in the same block)
-        GGC_REQUIRE(ctx, ring_cap < (1u << 24), GGC_E_UNSUPPORTED, "batch has more max-flow tiles than a queue entry addresses");
-        ring = scratch_t<unsigned long long>(ctx, S_GC_O, ring_cap + (AQ_WORDS + n_pt + 1) / 2 + 1 + 128 * 8 + 2 + (n_pt + 1) / 2 + 1);
-        if (!ring) return GGC_E_OOM;
-        aq = reinterpret_cast<int32_t*>(ring + ring_cap);
-        busy = aq + AQ_WORDS;
-    }
-    // one word per push tile: a neighbour pushed into it since its arc masks were last exact (k_build_graph has just written them)
+    GGC_REQUIRE(ctx, ring_cap < (1u << 24), GGC_E_UNSUPPORTED, "batch has more max-flow tiles than a queue entry addresses");
+    unsigned long long* ring = scratch_t<unsigned long long>(ctx, S_GC_O, ring_cap + (AQ_WORDS + n_pt + 1) / 2 + 1 + 128 * 8 + 2 + (n_pt + 1) / 2 + 1);
+    if (!ring) return GGC_E_OOM;
+    int32_t* aq = reinterpret_cast<int32_t*>(ring + ring_cap);
+    int32_t* busy = aq + AQ_WORDS;
+    long long* prof_dev = kn.mf_trace ? reinterpret_cast<long long*>(busy + ((n_pt + 3) & ~(size_t)1)) : nullptr;
+    // one word per push tile: a neighbour pushed into it since its arc masks were last exact.  k_build_graph writes exact
+    // masks for every pixel on a cold start; a warm start leaves the definite pixels alone, so their tiles' marks stay.
     int32_t* dirty = busy + ((n_pt + 3) & ~(size_t)1) + 2 * 128 * 8;
-    GGC_HIP(ctx, hipMemsetAsync(dirty, 0, sizeof(int32_t) * n_pt, st));
-    std::vector<int32_t> host;
-    long long* prof_dev = nullptr;                                         // GGC_MF_TRACE: visit-phase clocks of k_mf_pr_wave
-    if (std::getenv("GGC_MF_TRACE") != nullptr && ring) {
-        prof_dev = reinterpret_cast<long long*>(busy + ((n_pt + 3) & ~(size_t)1));          // (the scratch block is sized for it below)
-        GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, 128 * 8 * sizeof(long long), st));
-    }
+    if (masks_exact) GGC_HIP(ctx, hipMemsetAsync(dirty, 0, sizeof(int32_t) * n_pt, st));
+    if (prof_dev) GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, 128 * 8 * sizeof(long long), st));
     GGC_HIP(ctx, hipMemsetAsync(n_open, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_open_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, list_cur, n_open);
     GGC_LAUNCH_CHECK(ctx);
+    std::vector<int32_t> host;
     int rcode = read_i32(ctx, st, n_open, 1, host);
     if (rcode) return rcode;
     int n_cur = host[0];
     if (n_cur == 0) return GGC_OK;
-    const bool trace = std::getenv("GGC_MF_TRACE") != nullptr;
-    // schedule measured on MI355X (tools/mf_sweep.sh)
-    static const int n_launch = env_int("GGC_MF_PR_LAUNCHES", 12), n_inner = env_int("GGC_MF_PR_INNER", 8);
-    static const int n_launch0 = env_int("GGC_MF_PR_LAUNCHES0", 8);
-    static const int relax_rep = env_int("GGC_MF_RELAX_REP", 4);         // relabel launches per read-back of the next list's size
-    static const int tail_active = env_int("GGC_MF_TAIL_ACTIVE", 4000), tail_launch = env_int("GGC_MF_TAIL_LAUNCHES", 64);
     const int max_rounds = 4096;
     auto t_prev = std::chrono::steady_clock::now();
     double push_ms = 0.0;
     for (int round = 0; round < max_rounds; ++round) {
-        // Blocks walk their share of the list and load the next tile while they work on the current one, so a block
-        // should own several tiles: 1024 (push) / 2048 (relabel) blocks per 64 open images — one GrabCut lane — measured
-        // best (+6 % end to end over 8192); the caps grow with the batch a single call is given.  Late rounds (a handful
-        // of open images) are pure launch latency, and empty blocks add to it: never more blocks than tiles.
+        // Blocks walk their share of a list and load the next tile while they work on the current one, so a block should own
+        // several tiles: the grid caps are per 64 open images (one GrabCut lane) and grow with the batch a call is given.
+        // Late rounds (a handful of open images) are pure launch latency, and empty blocks add to it: never more blocks than tiles.
         const size_t scale = std::max<size_t>(1, ((size_t)n_cur + 32) / 64);
-        const int rl_grid = (int)std::min<size_t>(RELAX_GRID * scale, std::max<size_t>(64, (size_t)n_cur * tl.rt_x * tl.rt_y));
+        const int per_image = tl.rt_x * tl.rt_y;
         const int pr_grid = (int)std::min<size_t>(PUSH_GRID * scale, std::max<size_t>(64, (size_t)n_cur * tl.pt_x * tl.pt_y / 2));
-        static const bool relax_wave = RT == MF_RT && env_int("GGC_MF_RELAX_WAVE", 2) == 2;      // 1: the block-per-tile kernel
-        static const int rlw_cap = env_int("GGC_MF_RELAXW_GRID", 1024);
-        const int rlw_grid = (int)std::min<size_t>(rlw_cap * scale, std::max<size_t>(16, cdiv((size_t)n_cur * tl.rt_x * tl.rt_y, 4)));
+        const int rl_grid = (int)std::min<size_t>(RELAX_GRID * scale, std::max<size_t>(16, cdiv((size_t)n_cur * per_image, 4)));
         // ---- global relabel of the open images
         int relax_launches = 0;
         {
             ProfScope prof(ctx, st, "maxflow_relabel");
-            const int per_image = tl.rt_x * tl.rt_y;
-            static const bool tile_init = env_int0("GGC_MF_TILE_INIT", 1) != 0;
-            mf_zero3(st, rl_flag[0], n_rt * 2, rl_cnt, (relax_wave && tile_init) ? 3 : 0, nullptr, 0);
-            if (relax_wave && tile_init) {
-                hipLaunchKernelGGL(k_mf_rinit, dim3(cdiv(per_image, 4), n_cur), dim3(256), 0, st, d, tl, list_cur, snk, dist, rl_list[0], rl_flag[0],
-                                   rl_cnt);
-            } else {
-                if (relax_wave) hipLaunchKernelGGL(k_mf_dinit<false>, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
-                else hipLaunchKernelGGL(k_mf_dinit<true>, dim3(cdiv(d.P, 256), n_cur), dim3(256), 0, st, d, list_cur, snk, rc, dist, rmask);
-                hipLaunchKernelGGL(k_mf_list_all, dim3(cdiv((size_t)n_cur * per_image, 256)), dim3(256), 0, st, n_cur, list_cur, per_image,
-                                   rl_list[0], rl_flag[0], rl_cnt);
-            }
+            mf_zero3(st, rl_flag[0], n_rt * 2, rl_cnt, 3, nullptr, 0);
+            hipLaunchKernelGGL(k_mf_rinit, dim3(cdiv(per_image, 4), n_cur), dim3(256), 0, st, d, tl, list_cur, snk, dist, rl_list[0], rl_flag[0], rl_cnt);
+            auto relax = [&](int phase) {
+                int32_t *li = rl_list[phase & 1], *lo = rl_list[(phase + 1) & 1], *fi = rl_flag[phase & 1], *fo = rl_flag[(phase + 1) & 1];
+                if (prof_dev) hipLaunchKernelGGL(k_mf_relax_wave<true>, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt, li, lo, fi, fo);
+                else hipLaunchKernelGGL(k_mf_relax_wave<false>, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt, li, lo, fi, fo);
+            };
+            // k_mf_rinit starts the labels from the sink links and lists the tiles that have a pixel away from the sink; the
+            // first launches relax every listed tile (bandwidth work, plain stores).  With the asynchronous driver the long
+            // sparse rest of the front runs inside ONE launch that ends at the exact fixpoint (nothing to read back); without
+            // it the host reads the size of the next list every fourth launch.
             int phase = 0;
-            if (async_relax && relax_wave) {
-                // the first launches relax every tile of the open images (bandwidth work, plain stores); the long sparse rest of
-                // the front runs asynchronously inside one launch that ends at the fixpoint: nothing to read back
-                for (; phase < relax_dense; ++phase)
-                    if (trace && prof_dev) hipLaunchKernelGGL(k_mf_relax_wave<true>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt,
-                                       rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
-                    else hipLaunchKernelGGL(k_mf_relax_wave<false>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt,
-                                       rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
-                const int grid = (int)std::min<size_t>(async_grid * scale, std::max<size_t>(16, cdiv((size_t)n_cur * tl.rt_x * tl.rt_y, 16)));
+            if (kn.mf_async) {
+                for (; phase < kn.mf_relax_dense; ++phase) relax(phase);
+                const int grid = (int)std::min<size_t>(ASYNC_GRID * scale, std::max<size_t>(16, cdiv((size_t)n_cur * per_image, 16)));
                 if ((rcode = maxflow_relax_async(ctx, st, d, tl, rmask, dirty, rc, dist, rl_cnt + phase % 3, rl_list[phase & 1], rl_flag[phase & 1], ring, aq,
                                                  (int)n_rt, grid, err_flag)))
                     return rcode;
                 relax_launches = phase + 1;
-            } else
-            for (int guard = 0; guard < 100000; ++guard) {
-                for (int rep = 0; rep < relax_rep; ++rep, ++phase) {
-                    if (relax_wave)
-                        if (trace && prof_dev) hipLaunchKernelGGL(k_mf_relax_wave<true>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt,
-                                       rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
-                    else hipLaunchKernelGGL(k_mf_relax_wave<false>, dim3(rlw_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt,
-                                           rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
-                    else
-                        hipLaunchKernelGGL(k_mf_relax_list, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, rmask, dist, rl_cnt,
-                                           rl_list[phase & 1], rl_list[(phase + 1) & 1], rl_flag[phase & 1], rl_flag[(phase + 1) & 1]);
+            } else {
+                for (int guard = 0; guard < 100000; ++guard) {
+                    for (int rep = 0; rep < 4; ++rep, ++phase) relax(phase);
+                    GGC_LAUNCH_CHECK(ctx);
+                    if ((rcode = read_i32(ctx, st, rl_cnt + phase % 3, 1, host))) return rcode;   // size of the next frontier
+                    if (host[0] == 0) break;
                 }
-                GGC_LAUNCH_CHECK(ctx);
                 relax_launches = phase;
-                if ((rcode = read_i32(ctx, st, rl_cnt + phase % 3, 1, host))) return rcode;   // size of the next frontier
-                if (host[0] == 0) break;
             }
         }
         // ---- who still has work?  (active pixel = excess that can still reach the sink)
@@ -979,7 +579,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
         GGC_LAUNCH_CHECK(ctx);
         if ((rcode = read_i32(ctx, st, n_open, 8, host))) return rcode;
         const int n_next = host[0], total_active = host[7];
-        if (trace && prof_dev) {   // visit-phase clocks of the dense relabel launches of this round
+        if (kn.mf_trace) {   // diagnostics: visit-phase clocks of the dense relabel launches, active pixels / open images per round, the stragglers by image
             long long hh[64 * 8], h[5] = {0, 0, 0, 0, 0};
             GGC_HIP(ctx, hipStreamSynchronize(st));
             GGC_HIP(ctx, hipMemcpy(hh, prof_dev + 64 * 8, sizeof hh, hipMemcpyDeviceToHost));
@@ -988,124 +588,63 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             if (h[3] > 0)
                 std::fprintf(stderr, "    [relabel visits] %lld dense visits: per visit load+fill %.2f us, sweeps %.2f us (%.1f sweeps), write-back %.2f us\n",
                              h[3], 0.01 * h[0] / h[3], 0.01 * h[1] / h[3], (double)h[4] / h[3], 0.01 * h[2] / h[3]);
-        }
-        if (trace) {   // diagnostics: active pixels / open images per round
             std::vector<int32_t> act;
             if ((rcode = read_i32(ctx, st, active, B, act))) return rcode;
-            long long tot = 0;
-            for (int v : act) tot += v;
             const auto t_now = std::chrono::steady_clock::now();
             const double ms = std::chrono::duration<double, std::milli>(t_now - t_prev).count();
-            std::fprintf(stderr, "[ggc maxflow] round %d: open images %d, active pixels %lld, relabel launches %d, relabel+scan %.3f ms, previous push %.3f ms\n",
-                         round, n_next, tot, relax_launches, ms - push_ms, push_ms);
+            std::fprintf(stderr, "[ggc maxflow] round %d: open images %d, active pixels %d, relabel launches %d, relabel+scan %.3f ms, previous push %.3f ms\n",
+                         round, n_next, total_active, relax_launches, ms - push_ms, push_ms);
             t_prev = t_now;
+            if (n_next > 0 && n_next <= 12) {
+                std::fprintf(stderr, "    [open]");
+                for (int b = 0; b < B; ++b) if (act[b]) std::fprintf(stderr, " %d:%d", b, act[b]);
+                std::fprintf(stderr, "\n");
+            }
         }
         if (n_next == 0) return GGC_OK;
         std::swap(list_cur, list_nxt);
         n_cur = n_next;
-        // Hand-over.  The first rounds move most of the flow and keep the whole chip busy from one work list.  What is left
-        // (a few thousand active pixels in a batch of millions) is a chain of tiny dependent launches and read-backs here,
-        // and it is independent per image: one resident workgroup per open image finishes it in a single launch
-        // (ggc_maxflow_image.hip; the arc masks of this round's relabel are current, nothing has been pushed since).
-        if (handoff_active > 0 && total_active <= handoff_active && maxflow_image_fits(d)) {
-            int32_t* st2 = scratch_t<int32_t>(ctx, S_GC_H, (size_t)B);
-            if (!st2) return GGC_E_OOM;
-            GGC_HIP(ctx, hipMemsetAsync(st2, 0xff, sizeof(int32_t) * B, st));
-            hipLaunchKernelGGL(k_open_state, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, B, n_cur, list_cur, st2);
-            GGC_LAUNCH_CHECK(ctx);
-            return maxflow_image(ctx, st, d, st2, rc, ex, snk, dist, rmask, err_flag);
-        }
         // ---- push-relabel sweeps
         {
             ProfScope prof(ctx, st, "maxflow_push");
-            // few active pixels: their labels stay exact, so more (cheap) launches beat another global relabel
-            // first round: labels go stale fastest while most excess is still moving, an early relabel pays (12 vs 24: +3 %)
-            const bool tail = total_active <= tail_active;
-            // Tail rounds are chains of up to 64 dependent launches over a few tiles: latency, not work.  The open images are
-            // independent, so ONE launch with a resident workgroup per open image runs the whole push phase instead
-            // (ggc_maxflow_image.hip, push-only mode); the relabel stays here, on the batch-wide work lists.
-            // Measured (tools/mft_sweep.sh, batch 256, 4 lanes): 82.7 ms per GrabCut stage against 76.1 for the launch chains —
-            // the resident workgroups (150 KB of LDS each) keep the other lanes' kernels off their CUs, and the chains of one
-            // lane are what the other three lanes fill.  Off unless GGC_MF_IMAGE_TAIL=1.
-            static const int img_tail = std::getenv("GGC_MF_IMAGE_TAIL") ? env_int("GGC_MF_IMAGE_TAIL", 2) : 2;
-            static const int img_tail_passes = env_int("GGC_MF_IMAGE_TAIL_PASSES", 16), img_tail_inner = env_int("GGC_MF_IMAGE_TAIL_INNER", 32);
-            if (tail && img_tail == 1 && err_flag && maxflow_image_fits(d)) {
-                int32_t* st2 = scratch_t<int32_t>(ctx, S_GC_H, (size_t)B);
-                if (!st2) return GGC_E_OOM;
-                GGC_HIP(ctx, hipMemsetAsync(st2, 0xff, sizeof(int32_t) * B, st));
-                hipLaunchKernelGGL(k_open_state, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, B, n_cur, list_cur, st2);
-                GGC_LAUNCH_CHECK(ctx);
-                if ((rcode = maxflow_image(ctx, st, d, st2, rc, ex, snk, dist, rmask, err_flag, img_tail_passes, img_tail_inner))) return rcode;
-                continue;
-            }
-            if (round > 0 && total_active <= async_push_active) {
-                // sparse round: one asynchronous launch chases the excess from tile to tile (chains of at most async_gen hops)
-                const int waves = (int)std::min<long long>(4ll * async_grid * (long long)scale, std::max<long long>(64, total_active / 4));
-                static const int gen_tail = env_int("GGC_MF_ASYNC_GEN_TAIL", 24), gen_tail_active = env_int("GGC_MF_ASYNC_GEN_TAIL_ACTIVE", 1000);
-                const int gen_now = total_active <= gen_tail_active ? gen_tail : async_gen;
-                if ((rcode = maxflow_push_async(ctx, st, d, tl, async_th, async_inner, gen_now, rc, ex, snk, dist, rmask, dirty, pr_cnt, pt_list[0], (int)n_pt,
-                                                busy, ring, aq, waves, err_flag, trace ? prof_dev : nullptr)))
+            if (kn.mf_async && round > 0 && total_active <= kn.mf_async_push_active) {
+                // sparse round: one asynchronous launch chases the excess from tile to tile (chains of at most async_hops hops)
+                const int waves = (int)std::min<long long>(4ll * ASYNC_GRID * (long long)scale, std::max<long long>(64, total_active / 4));
+                if ((rcode = maxflow_push_async(ctx, st, d, tl, kn.mf_async_tile, kn.mf_async_sweeps, kn.mf_async_hops, rc, ex, snk, dist, rmask, dirty, pr_cnt, pt_list[0], (int)n_pt,
+                                                busy, ring, aq, waves, err_flag, prof_dev)))
                     return rcode;
-                if (trace) {
+                if (kn.mf_trace) {
                     GGC_HIP(ctx, hipStreamSynchronize(st));
                     push_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
-                    if (prof_dev) {
-                        long long hh[128 * 8], h[7] = {0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-                        GGC_HIP(ctx, hipMemcpy(hh, prof_dev, sizeof hh, hipMemcpyDeviceToHost));
-                        GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, sizeof hh, st));
-                        for (int i = 0; i < 64; ++i) for (int k = 0; k < 7; ++k) h[k] += hh[i * 8 + k];
-                        for (int i = 0; i < 64; ++i) for (int k = 0; k < 3; ++k) g[k] += hh[(64 + i) * 8 + k];
-                        if (h[3] > 0)
-                            std::fprintf(stderr, "    [async visit] load+fill %.2f us, sweeps %.2f us (%.1f sweeps), write-back+drain %.2f us\n", 0.01 * g[0] / h[3],
-                                         0.01 * g[1] / h[3], (double)g[2] / h[3], 0.01 * (h[1] - g[0] - g[1]) / h[3]);
-                        if (h[6] > 0)
-                            std::fprintf(stderr, "    [async push] %d waves alive %.1f us on average; %lld visits (%lld followed): per visit wait+lock %.2f us, "
-                                         "visit %.2f us, hand-over %.2f us\n", waves, 0.01 * h[5] / h[6], h[3], h[4], h[3] ? 0.01 * h[0] / h[3] : 0.0,
-                                         h[3] ? 0.01 * h[1] / h[3] : 0.0, h[3] ? 0.01 * h[2] / h[3] : 0.0);
-                    }
+                    long long hh[128 * 8], h[7] = {0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+                    GGC_HIP(ctx, hipMemcpy(hh, prof_dev, sizeof hh, hipMemcpyDeviceToHost));
+                    GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, sizeof hh, st));
+                    for (int i = 0; i < 64; ++i) for (int k = 0; k < 7; ++k) h[k] += hh[i * 8 + k];
+                    for (int i = 0; i < 64; ++i) for (int k = 0; k < 3; ++k) g[k] += hh[(64 + i) * 8 + k];
+                    if (h[3] > 0)
+                        std::fprintf(stderr, "    [async visit] load+fill %.2f us, sweeps %.2f us (%.1f sweeps), write-back+drain %.2f us\n", 0.01 * g[0] / h[3],
+                                     0.01 * g[1] / h[3], (double)g[2] / h[3], 0.01 * (h[1] - g[0] - g[1]) / h[3]);
+                    if (h[6] > 0)
+                        std::fprintf(stderr, "    [async push] %d waves alive %.1f us on average; %lld visits (%lld followed): per visit wait+lock %.2f us, "
+                                     "visit %.2f us, hand-over %.2f us\n", waves, 0.01 * h[5] / h[6], h[3], h[4], h[3] ? 0.01 * h[0] / h[3] : 0.0,
+                                     h[3] ? 0.01 * h[1] / h[3] : 0.0, h[3] ? 0.01 * h[2] / h[3] : 0.0);
                 }
                 continue;
             }
-            const int launches = tail ? tail_launch : (round == 0 ? n_launch0 : n_launch);
-            // sweeps per visit: measured flat from 6 to 12 and worse either side, in the tail too (32 sweeps: -7 % end to
-            // end; a pixel whose admissible arcs saturate keeps the loop alive by relabelling one step per sweep)
-            static const int tail_inner = env_int("GGC_MF_TAIL_INNER", 8);
-            const int sweeps = tail ? tail_inner : n_inner;
+            // dense round.  First round: labels go stale fastest while most excess is still moving, an early relabel pays
+            // (8 launches vs 12: +3 %); sweeps per visit measured flat from 6 to 12 and worse either side.  Without the
+            // asynchronous driver the tail rounds (few active pixels, labels stay exact) run longer chains of cheap launches.
+            const bool tail = !kn.mf_async && total_active <= 4000;
+            const int launches = tail ? 64 : (round == 0 ? kn.mf_dense_launches0 : kn.mf_dense_launches);
             // an active pixel opens at most its own tile: empty blocks only add dispatch time to launches that are pure latency
-            static const int grid_per_active = env_int("GGC_MF_GRID_PER_ACTIVE", 2);
-            const int grid = (int)std::min<long long>(pr_grid, std::max<long long>(128, (long long)total_active * grid_per_active));
-            static const int pr_wgrid_cap = env_int("GGC_MF_PRW_GRID", 1024);
-            static const int ppt = env_int("GGC_MF_PPT", 1);   // 2 measured 3 % slower end to end: the longer visit outweighs the tiles in flight
-            static const int pr_wave = env_int0("GGC_MF_PR_WAVE", 0);   // 1: wave-per-tile kernel (same speed; its visit-phase clocks are what GGC_MF_TRACE prints)
-            const int wgrid = (int)std::min<long long>((long long)pr_wgrid_cap * (long long)scale, std::max<long long>(32, (long long)total_active * grid_per_active / 4));
-            for (int phase = 0; phase < launches; ++phase) {
-                if (pr_wave && trace)
-                    hipLaunchKernelGGL(k_mf_pr_wave<true>, dim3(wgrid), dim3(256), 0, st, d, tl, phase, sweeps, prof_dev, rc, ex, snk, dist, rmask, dirty, pr_cnt,
-                                       pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
-                else if (pr_wave)
-                    hipLaunchKernelGGL(k_mf_pr_wave<false>, dim3(wgrid), dim3(256), 0, st, d, tl, phase, sweeps, prof_dev, rc, ex, snk, dist, rmask, dirty, pr_cnt,
-                                       pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
-                else if (ppt == 2)
-                    hipLaunchKernelGGL((k_mf_pr_list<2>), dim3(grid), dim3(PT_N / 2), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, rmask, dirty, pr_cnt,
-                                       pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
-                else
-                    hipLaunchKernelGGL((k_mf_pr_list<1>), dim3(grid), dim3(PT_N), 0, st, d, tl, phase, sweeps, rc, ex, snk, dist, rmask, dirty, pr_cnt,
-                                       pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
-            }
+            const int grid = (int)std::min<long long>(pr_grid, std::max<long long>(128, 2ll * total_active));
+            for (int phase = 0; phase < launches; ++phase)
+                hipLaunchKernelGGL((k_mf_pr_list<1>), dim3(grid), dim3(PT_N), 0, st, d, tl, phase, kn.mf_dense_sweeps, rc, ex, snk, dist, rmask, dirty, pr_cnt,
+                                   pt_list[phase & 1], pt_list[(phase + 1) & 1], pt_flag[phase & 1], pt_flag[(phase + 1) & 1]);
             GGC_LAUNCH_CHECK(ctx);
-            if (trace) {
+            if (kn.mf_trace) {
                 GGC_HIP(ctx, hipStreamSynchronize(st));
                 push_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
-                if (pr_wave && prof_dev) {
-                    long long hh[64 * 8], h[6] = {0, 0, 0, 0, 0, 0};
-                    GGC_HIP(ctx, hipMemcpy(hh, prof_dev, sizeof hh, hipMemcpyDeviceToHost));
-                    GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, sizeof hh, st));
-                    for (int i = 0; i < 64; ++i) for (int k = 0; k < 6; ++k) h[k] += hh[i * 8 + k];
-                    if (h[3] > 0)
-                        std::fprintf(stderr, "    [push visits] %lld visits in %d launches (grid %d x 4 waves): per visit load+fill %.2f us, sweeps %.2f us "
-                                     "(%.1f sweeps, %.1f active pixels per sweep), write-back %.2f us\n", h[3], launches, wgrid,
-                                     0.01 * h[0] / h[3], 0.01 * h[1] / h[3], (double)h[4] / h[3], h[4] ? (double)h[5] / h[4] : 0.0, 0.01 * h[2] / h[3]);
-                }
             }
         }
     }

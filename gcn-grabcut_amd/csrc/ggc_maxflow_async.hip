@@ -541,9 +541,10 @@ int maxflow_push_async(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const MfTi
     th = th >= 32 ? 32 : (th >= 16 ? 16 : 8);
     const int bt_x = tl.pt_x, bt_y = cdiv(d.H, th), cap = bt_x * bt_y * d.B;
     gen_max = std::min(gen_max, 127);
-    static const int follow = [] { const char* e = std::getenv("GGC_MF_ASYNC_FOLLOW"); return e ? std::atoi(e) : 1; }();
-    static const int park = [] { const char* e = std::getenv("GGC_MF_ASYNC_PARK"); return e ? std::max(1, std::atoi(e)) : 255; }();
-    static const int chase = [] { const char* e = std::getenv("GGC_MF_ASYNC_CHASE"); return e ? std::max(1, std::atoi(e)) : 1; }();   // > 1 measured slower: most sparse-round excess is trapped and only climbs labels faster
+    // Fixed after the round-2 measurements: the wave that finishes a visit FOLLOWS the front into one of the
+    // tiles it would have queued (74.6 -> 69.9 ms per stage); chasing a unit of excess inside a sweep (chase > 1) and
+    // parking pixels that only climb (park < 255) measured slower / without effect, so both stay off.
+    const int follow = 1, park = 255, chase = 1;
     mf_zero3(st, reinterpret_cast<int32_t*>(ring), (size_t)cap * 2, q, AQ_WORDS, state, (size_t)cap);
     hipLaunchKernelGGL(k_aq_fill_big, dim3(cdiv(n_list_max, 256)), dim3(256), 0, st, count, list, tl.pt_x, tl.pt_y, th, bt_x, bt_y, state, ring, q,
                        gen_max);

@@ -1045,11 +1045,8 @@ static int launch_aggregate_graph_t(ggc_ctx* ctx, hipStream_t st, int G, const i
 // [nodes-per-graph, SW] tile fits half a CU's LDS with a little head-room over the mean graph size (a larger
 // graph falls back per block); 0 = use the direct gather.
 static int agg_graph_slice(int N, int G) {
-    static const bool direct_only = [] { const char* e = std::getenv("GGC_AGG_DIRECT"); return e && e[0] == '1'; }();
-    if (G <= 0 || direct_only) return 0;
+    if (G <= 0 || knobs().agg_direct) return 0;
     const double want = 1.02 * (double)N / G;
-    static const int force = [] { const char* e = std::getenv("GGC_AGG_SW"); return e ? std::atoi(e) : 0; }();
-    if (force == 16 && want <= AggGraph<16>::CAP) return 16;
     return want <= AggGraph<32>::CAP ? 32 : want <= AggGraph<16>::CAP ? 16 : 0;
 }
 
@@ -1090,8 +1087,7 @@ static int launch_aggregate(ggc_ctx* ctx, hipStream_t st, int N, const float* xw
     ProfScope prof(ctx, st, MODE == 0 ? "gcn_aggregate" : "sage_aggregate");
     if (ag.sw == 32) return launch_aggregate_graph<D, MODE, 32>(ctx, st, ag, xw, row_ptr, col, dis, bias, gate, h, out);
     if (ag.sw == 16) return launch_aggregate_graph<D, MODE, 16>(ctx, st, ag, xw, row_ptr, col, dis, bias, gate, h, out);
-    static const int threads = [] { const char* e = std::getenv("GGC_AGG_THREADS"); const int t = e ? std::atoi(e) : 256;
-                                    return (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) ? t : 256; }();
+    constexpr int threads = 256;
     const int rows_per_block = AggCfg<D>::RPW * (threads / 64);
     hipLaunchKernelGGL((k_aggregate<D, MODE>), dim3(cdiv(N, rows_per_block)), dim3(threads), 0, st,
                        N, xw, row_ptr, col, dis, bias, gate, h, out);

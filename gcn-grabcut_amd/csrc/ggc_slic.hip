@@ -669,7 +669,7 @@ using namespace ggc;
 static int enforce_connectivity(ggc_ctx* ctx, hipStream_t st, int B, int H, int W, const int32_t* raw, int min_size,
                                 int max_size, int32_t* segments, int32_t* n_nodes) {
     const size_t P = (size_t)H * W;
-    if (std::getenv("GGC_SLIC_SEQ_CONNECTIVITY")) {   // literal raster-scan replay, one thread per image (A/B reference)
+    if (knobs().slic_seq_connectivity) {   // literal raster-scan replay, one thread per image (A/B reference)
         int32_t* queue = scratch_t<int32_t>(ctx, S_SLIC_AUX3, (size_t)B * (size_t)std::max(max_size, 1));
         if (!queue) return GGC_E_OOM;
         GGC_HIP(ctx, hipMemsetAsync(segments, 0xFF, sizeof(int32_t) * (size_t)B * P, st));

@@ -51,13 +51,13 @@ class Engine:
     def lanes(self, n: int):
         """n (engine, stream) pairs with private contexts for work that is independent per image.  GrabCut's
         max-flow ends in rounds with a handful of open images that are pure launch latency; running sub-batches
-        on separate streams lets one sub-batch's tail overlap another's bandwidth-bound rounds."""
-        if self._lanes is None or len(self._lanes) != n:
-            if getattr(self, "_pool", None) is not None:
-                self._pool.shutdown(wait=True)       # the lane count changed: the old worker threads end here, not at exit
-            self._pool = None
-            self._lanes = [(Engine(self.index, private_context=True), torch.cuda.Stream(self.device)) for _ in range(n)]
-        return self._lanes
+        on separate streams lets one sub-batch's tail overlap another's bandwidth-bound rounds.  The list only
+        grows: streams keep their hardware queue, and two lanes that share a queue serialise."""
+        if self._lanes is None:
+            self._lanes = []
+        while len(self._lanes) < n:
+            self._lanes.append((Engine(self.index, private_context=True), torch.cuda.Stream(self.device)))
+        return self._lanes[:n]
 
     def grabcut_lanes(self, image, mask, n_iter=5, mode=0, seed=0, n_lanes=4, bgd=None, fgd=None):
         """grabcut() on n_lanes contiguous sub-batches at once; same results (image b keeps seed + b)."""
@@ -85,7 +85,9 @@ class Engine:
                 binary[lo:hi].copy_(out[0])
             stream.synchronize()
 
-        if getattr(self, "_pool", None) is None or self._pool._max_workers != n_lanes - 1:
+        if getattr(self, "_pool", None) is None or self._pool._max_workers < n_lanes - 1:
+            if getattr(self, "_pool", None) is not None:
+                self._pool.shutdown(wait=True)
             self._pool = ThreadPoolExecutor(max_workers=n_lanes - 1, thread_name_prefix="ggc-lane")
         futures = [self._pool.submit(run, i) for i in range(1, n_lanes)]
         out = self.grabcut(image[:bounds[1]], mask[:bounds[1]], n_iter, mode, None, seed, bgd[:bounds[1]], fgd[:bounds[1]])
@@ -205,17 +207,17 @@ class Engine:
                       out.data_ptr())
         return out
 
-    def clean_mask(self, mask, min_area_ratio=0.002, keep_largest=False) -> torch.Tensor:
+    def clean_mask(self, mask, min_area_ratio=0.002, keep_largest=False, out=None) -> torch.Tensor:
         b, h, w = mask.shape
-        out = torch.empty_like(mask)
+        if out is None:
+            out = torch.empty_like(mask)
         self.ctx.call("ggc_clean_mask", self._stream(), b, h, w, mask.data_ptr(), float(min_area_ratio),
                       int(bool(keep_largest)), out.data_ptr())
         return out
 
-    def compose(self, bgr, binary, alpha=0.45, tint_bgr=(100, 220, 0)):
+    def compose(self, bgr, binary, alpha=0.45, tint_bgr=(100, 220, 0), out=None):
         b, h, w, _ = bgr.shape
-        overlay = self.empty(b, h, w, 3, dtype=torch.uint8)
-        rgba = self.empty(b, h, w, 4, dtype=torch.uint8)
+        overlay, rgba = out if out is not None else (self.empty(b, h, w, 3, dtype=torch.uint8), self.empty(b, h, w, 4, dtype=torch.uint8))
         self.ctx.call("ggc_compose_outputs", self._stream(), b, h, w, bgr.data_ptr(), binary.data_ptr(), float(alpha),
                       int(tint_bgr[0]), int(tint_bgr[1]), int(tint_bgr[2]), overlay.data_ptr(), rgba.data_ptr())
         return overlay, rgba
@@ -228,6 +230,29 @@ class Engine:
         self.ctx.call("ggc_mask_iou", self._stream(), b, h, w, pred.data_ptr(), gt.data_ptr(), iou.data_ptr(),
                       cnt.data_ptr())
         return iou, cnt
+
+
+def merge_graphs(parts: Sequence[DeviceGraphs], segments: torch.Tensor) -> DeviceGraphs:
+    """The graphs of consecutive chunks of a batch as ONE packed batch (what build_graphs returns for the whole batch):
+    node-indexed arrays are concatenated, edge endpoints shifted by the nodes that precede their chunk."""
+    if len(parts) == 1:
+        return parts[0]
+    node_ptr, edge_ptr, src, dst = [np.zeros(1, np.int64)], [np.zeros(1, np.int64)], [], []
+    n0 = e0 = 0
+    for g in parts:
+        node_ptr.append(g.node_ptr_host[1:] + n0)
+        edge_ptr.append(g.edge_ptr_host[1:] + e0)
+        src.append(g.edge_src + n0 if n0 else g.edge_src)
+        dst.append(g.edge_dst + n0 if n0 else g.edge_dst)
+        n0 += int(g.node_ptr_host[-1])
+        e0 += int(g.edge_ptr_host[-1])
+    node_ptr, edge_ptr = np.concatenate(node_ptr), np.concatenate(edge_ptr)
+    dev = segments.device
+    return DeviceGraphs(segments, torch.cat([g.n_nodes for g in parts]), node_ptr, edge_ptr,
+                        torch.from_numpy(node_ptr.astype(np.int32)).to(dev, non_blocking=True),
+                        torch.cat([g.x for g in parts]), torch.cat([g.centroids for g in parts]),
+                        torch.cat([g.area_ratio for g in parts]), torch.cat(src), torch.cat(dst),
+                        torch.cat([g.edge_attr for g in parts]))
 
 
 _engines: dict[int, Engine] = {}

@@ -141,10 +141,13 @@ class GCNGrabCutPipeline:
     """
 
     def __init__(self, model, sp_config: Optional[SuperpixelGraphConfig] = None,
-                 gc_config: Optional[GrabCutConfig] = None, device: str = "cuda", grabcut_lanes: int = 4, engine=None):
+                 gc_config: Optional[GrabCutConfig] = None, device: str = "cuda", grabcut_lanes: int = 4, engine=None,
+                 chunks: int = 1, chunk_ratio: float = 0.8):
         from ._engine import get_engine
         self._eng = engine if engine is not None else get_engine(device)
         self.grabcut_lanes = int(grabcut_lanes)   # additive: concurrent sub-batches of the GrabCut stage (batched calls only)
+        self.chunks = int(chunks)                 # additive: chunks of the software pipeline of segment_batch_device (1 = off, the default: measured no faster)
+        self.chunk_ratio = float(chunk_ratio)
         self.model = model.to(self._eng.device)
         self.device = device
         self.sp_config = sp_config or SuperpixelGraphConfig()
@@ -204,33 +207,17 @@ class GCNGrabCutPipeline:
         return out
 
     # ------------------------------------------------------------ batched, device resident
-    def segment_batch_device(self, bgr, threshold_fg: float = 0.55, threshold_bg: float = 0.55,
-                             refine_iters: int = 0, min_area_ratio: float = 0.002, keep_largest: bool = False,
-                             edge_aware: bool = True, filter_radius: int = 8, compose: bool = True,
-                             timing: Optional[dict] = None, grabcut_lanes: Optional[int] = None) -> dict:
-        """bgr: (B,H,W,3) uint8 tensor on the pipeline's device.  Returns device tensors."""
-        import torch
-        eng, cfg = self._eng, self.sp_config
-        cs = self.gc_config.color_space.lower()
-        if cs not in ("rgb", "hsv", "lab"):
-            raise ValueError(f"unknown color_space '{cs}': rgb | hsv | lab")
-        if not cfg.use_lab:
-            raise NotImplementedError("use_lab=False is not on the MI355X hot path")
-
-        def tick():
-            if timing is not None:
-                torch.cuda.synchronize(eng.device)
-            return time.perf_counter()
-
-        t = tick()
+    def _front(self, eng, bgr, threshold_fg, threshold_bg, edge_aware, filter_radius, tick=None, timing=None):
+        """Stages 1-3 on the current stream: colour prep, SLIC, graph, network, trimap, seeding.  -> (seg, graphs, probs, trimap)"""
+        cfg = self.sp_config
+        t = tick() if tick else 0.0
         lab, hsv, gray, grad = eng.preprocess(bgr)
         seg, n_nodes = eng.slic(lab, cfg.n_segments, cfg.compactness, cfg.sigma)
         graphs = eng.build_graphs(seg, n_nodes, lab, hsv, grad, cfg.connectivity, cfg.n_nonlocal)
         if timing is not None:
             timing["graph_build"] = tick() - t
             timing["data_prep"] = 0.0          # the graph is already in HBM: nothing to copy
-
-        t = tick()
+        t = tick() if tick else 0.0
         if self.model.training:
             self.model.eval()
         probs = eng.predict_probs(self.model, graphs)
@@ -239,11 +226,58 @@ class GCNGrabCutPipeline:
         if timing is not None:
             timing["gcn_inference"] = tick() - t
         trimap = eng.seed_from_prior(trimap, graphs.x[:, 16:19], graphs.node_ptr, seg, 0.1)
+        return seg, graphs, probs, trimap
+
+    @staticmethod
+    def chunk_plan(b: int, n_chunks: int, ratio: float = 0.8) -> list[tuple[int, int]]:
+        """Contiguous chunks of a batch for the software pipeline, each `ratio` times the size of the one before it: the
+        GrabCut of a chunk starts when its trimaps exist, so later chunks start later and get fewer images to end together."""
+        n_chunks = max(1, min(int(n_chunks), b))
+        w = [ratio ** k for k in range(n_chunks)]
+        cuts, acc = [0], 0.0
+        for k in range(n_chunks - 1):
+            acc += w[k]
+            cuts.append(min(b - (n_chunks - 1 - k), max(cuts[-1] + 1, int(round(b * acc / sum(w))))))
+        cuts.append(b)
+        return [(cuts[k], cuts[k + 1]) for k in range(n_chunks)]
+
+    def segment_batch_device(self, bgr, threshold_fg: float = 0.55, threshold_bg: float = 0.55,
+                             refine_iters: int = 0, min_area_ratio: float = 0.002, keep_largest: bool = False,
+                             edge_aware: bool = True, filter_radius: int = 8, compose: bool = True,
+                             timing: Optional[dict] = None, grabcut_lanes: Optional[int] = None,
+                             chunks: Optional[int] = None) -> dict:
+        """bgr: (B,H,W,3) uint8 tensor on the pipeline's device.  Returns device tensors.
+
+        Large batches run as a software pipeline (additive, same results): the batch is cut into `chunks` contiguous
+        chunks; the front stages of chunk k+1 run on the caller's stream while the GrabCut / clean-up of chunk k runs on a
+        lane of its own (private context, stream and host thread).  Images are independent and image b keeps seed + b, so
+        every output equals the one-chunk run bit for bit."""
+        import torch
+        eng, cfg = self._eng, self.sp_config
+        cs = self.gc_config.color_space.lower()
+        if cs not in ("rgb", "hsv", "lab"):
+            raise ValueError(f"unknown color_space '{cs}': rgb | hsv | lab")
+        if not cfg.use_lab:
+            raise NotImplementedError("use_lab=False is not on the MI355X hot path")
+        b = bgr.size(0)
+        want = self.grabcut_lanes if grabcut_lanes is None else int(grabcut_lanes)   # (an argument, so that concurrent callers do not mutate the pipeline)
+        n_chunks = self.chunks if chunks is None else int(chunks)
+        if n_chunks <= 0:                          # 0: one chunk per GrabCut lane once every chunk gets a lane's worth of images
+            n_chunks = max(want, 1) if b >= 16 * max(want, 1) else 1
+        if n_chunks > 1 and b >= 2 * n_chunks:
+            return self._segment_pipelined(bgr, self.chunk_plan(b, n_chunks, self.chunk_ratio), cs, threshold_fg, threshold_bg,
+                                           refine_iters, min_area_ratio, keep_largest, edge_aware, filter_radius, compose, timing)
+
+        def tick():
+            if timing is not None:
+                torch.cuda.synchronize(eng.device)
+            return time.perf_counter()
+
+        seg, graphs, probs, trimap = self._front(eng, bgr, threshold_fg, threshold_bg, edge_aware, filter_radius, tick, timing)
 
         t = tick()
         mask = trimap.clone()
-        want = self.grabcut_lanes if grabcut_lanes is None else int(grabcut_lanes)   # (an argument, so that concurrent callers do not mutate the pipeline)
-        lanes = want if bgr.size(0) >= 8 * max(want, 1) else 1
+        lanes = want if b >= 8 * max(want, 1) else 1
         gc_img = bgr if cs == "rgb" else eng.convert_color8(bgr, cs)      # reference grabcut.py:73-79
         binary, mask, bgd, fgd = eng.grabcut_lanes(gc_img, mask, self.gc_config.n_iter, 0, self.gc_config.seed, lanes)
         if refine_iters > 0:
@@ -259,6 +293,89 @@ class GCNGrabCutPipeline:
             out["overlay"], out["rgba"] = eng.compose(bgr, cleaned)
         if timing is not None:
             timing["postprocess"] = tick() - t
+        return out
+
+    def _segment_pipelined(self, bgr, plan, cs, threshold_fg, threshold_bg, refine_iters, min_area_ratio, keep_largest,
+                           edge_aware, filter_radius, compose, timing) -> dict:
+        """The software pipeline behind segment_batch_device: chunk k's GrabCut lane starts as soon as chunk k's trimaps are
+        on the device; the caller's stream goes on with chunk k+1's SLIC / graph / network / trimap."""
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        from ._engine import merge_graphs
+        eng = self._eng
+        dev = eng.device
+        b, h, w, _ = bgr.shape
+        n = len(plan)
+        caller = torch.cuda.current_stream(dev)
+        lanes = eng.lanes(n)
+        if getattr(self, "_chunk_pool", None) is None or self._chunk_pool._max_workers != n:
+            if getattr(self, "_chunk_pool", None) is not None:
+                self._chunk_pool.shutdown(wait=True)
+            self._chunk_pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="ggc-chunk")
+        seg = eng.empty(b, h, w, dtype=torch.int32)
+        trimap = eng.empty(b, h, w, dtype=torch.uint8)
+        mask = eng.empty(b, h, w, dtype=torch.uint8)
+        cleaned = eng.empty(b, h, w, dtype=torch.uint8)
+        overlay = eng.empty(b, h, w, 3, dtype=torch.uint8) if compose else None
+        rgba = eng.empty(b, h, w, 4, dtype=torch.uint8) if compose else None
+        n_iter, seed = self.gc_config.n_iter, self.gc_config.seed
+        t_host = time.perf_counter()
+        stamps = []                                   # per chunk: events around its front stages / its lane's work
+
+        def lane_work(k, lo, hi, ready, ev):
+            leng, stream = lanes[k]
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(stream):
+                stream.wait_event(ready)              # the chunk's trimap, written on the caller's stream
+                if ev is not None:
+                    ev[0].record(stream)
+                img = bgr[lo:hi]
+                gc_img = img if cs == "rgb" else leng.convert_color8(img, cs)
+                m = mask[lo:hi]
+                binary, _, bgd, fgd = leng.grabcut(gc_img, m, n_iter, 0, None, seed + lo)
+                if refine_iters > 0:
+                    binary, _, bgd, fgd = leng.grabcut(gc_img, m, refine_iters, 2, None, seed + lo, bgd, fgd)
+                if ev is not None:
+                    ev[1].record(stream)
+                leng.clean_mask(binary, min_area_ratio, keep_largest, out=cleaned[lo:hi])
+                if compose:
+                    leng.compose(img, cleaned[lo:hi], out=(overlay[lo:hi], rgba[lo:hi]))
+                if ev is not None:
+                    ev[2].record(stream)
+                done = torch.cuda.Event()
+                done.record(stream)
+            return done
+
+        futures, parts = [], []
+        for k, (lo, hi) in enumerate(plan):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timing is not None else None
+            if ev is not None:
+                ev[3].record(caller)
+            s_k, g_k, p_k, t_k = self._front(eng, bgr[lo:hi], threshold_fg, threshold_bg, edge_aware, filter_radius)
+            seg[lo:hi].copy_(s_k)
+            trimap[lo:hi].copy_(t_k)
+            mask[lo:hi].copy_(t_k)
+            if ev is not None:
+                ev[4].record(caller)
+            ready = torch.cuda.Event()
+            ready.record(caller)
+            parts.append((g_k, p_k))
+            stamps.append(ev)
+            futures.append(self._chunk_pool.submit(lane_work, k, lo, hi, ready, ev))
+        graphs = merge_graphs([g for g, _ in parts], seg)            # under the lanes' GrabCut
+        probs = torch.cat([p for _, p in parts])
+        for f in futures:
+            caller.wait_event(f.result())             # whatever the caller enqueues next sees the lanes' outputs
+        out = {"binary_mask": cleaned, "trimap": trimap, "segments": seg, "graphs": graphs, "probs": probs, "gc_mask": mask}
+        if compose:
+            out["overlay"], out["rgba"] = overlay, rgba
+        if timing is not None:                        # stage times from stream events (the stages overlap: they add up to more than the wall time)
+            torch.cuda.synchronize(dev)
+            front = sum(e[3].elapsed_time(e[4]) for e in stamps) / 1e3
+            timing["graph_build"], timing["data_prep"], timing["gcn_inference"] = front, 0.0, 0.0
+            timing["grabcut"] = sum(e[0].elapsed_time(e[1]) for e in stamps) / 1e3
+            timing["postprocess"] = sum(e[1].elapsed_time(e[2]) for e in stamps) / 1e3
+            timing["wall"] = time.perf_counter() - t_host
         return out
 
     def segment_batch(self, images: Sequence[np.ndarray], **kwargs) -> list[SegmentationResult]:

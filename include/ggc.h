@@ -21,6 +21,23 @@
  *   - A context is bound to one device and must be used by one host thread at
  *     a time.  Scratch memory grows monotonically inside the context and is
  *     released by ggc_ctx_destroy().
+ *
+ * Environment switches (all optional; the library reads them ONCE per process,
+ * through one function, ggc::knobs() in csrc/ggc_context.hip; none changes a
+ * result — tests/test_maxflow_variants_gpu.py holds the max-flow ones to that):
+ *   GGC_MF_TRACE=1                per-round max-flow diagnostics on stderr (blocking)
+ *   GGC_MF_WARM=0                 cold max-flow start in every GrabCut iteration (default 1: keep the n-link flow)
+ *   GGC_MF_ASYNC=0                host-driven work lists only (default 1: sparse phases as one asynchronous launch each)
+ *   GGC_MF_ASYNC_PUSH_ACTIVE=n    push rounds with <= n active pixels run asynchronously (10000)
+ *   GGC_MF_ASYNC_TILE=8|16|32     rows of the asynchronous push tile (8)
+ *   GGC_MF_ASYNC_HOPS=n           longest chain of tile visits in an asynchronous push launch (24)
+ *   GGC_MF_ASYNC_SWEEPS=n         sweeps per asynchronous push visit (12)
+ *   GGC_MF_DENSE_LAUNCHES0=n / GGC_MF_DENSE_LAUNCHES=n   push launches of the first / a later dense round (8 / 12)
+ *   GGC_MF_DENSE_SWEEPS=n         sweeps per dense push visit (8)
+ *   GGC_MF_RELAX_DENSE=n          work-list launches of a global relabel before the asynchronous launch takes over (2)
+ *   GGC_AGG_DIRECT=1              GCNConv gather straight from L2 instead of the graph-resident kernel
+ *   GGC_SLIC_SEQ_CONNECTIVITY=1   literal one-thread-per-image replay of skimage's connectivity pass (A/B reference)
+ * The Python binding adds GGC_HIP_LIBRARY=<path> (load another build of the library, tools/build_variant.sh).
  */
 #ifndef GGC_H
 #define GGC_H

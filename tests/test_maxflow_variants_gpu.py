@@ -1,9 +1,9 @@
-"""Every driver of the max-flow gives the oracle's masks.
+"""Every schedule of the max-flow gives the oracle's masks.
 
-The cut of an integer network is canonical, so who drives the rounds (host work lists, asynchronous single-launch
-phases, the wave-per-tile dense kernel, one workgroup per image, the pooled kernel, the hybrid hand-over) must not
-change a single pixel.  The drivers are selected by environment variables the library reads ONCE per process, so each
-variant runs in its own interpreter (one at a time: a GPU box admits few processes on its card)."""
+The cut of an integer network is canonical, so who drives the rounds (host work lists or asynchronous single-launch
+phases), how long a round is and whether the flow of the previous GrabCut iteration is kept must not change a single
+pixel.  The switches are the documented GGC_MF_* variables of include/ggc.h, which the library reads ONCE per process,
+so each variant runs in its own interpreter (one at a time: a GPU box admits few processes on its card)."""
 import os
 import subprocess
 import sys
@@ -45,17 +45,13 @@ print("variant ok")
 """
 
 VARIANTS = {
-    "host_work_lists": {"GGC_MF_ASYNC_RELAX": "0", "GGC_MF_ASYNC_PUSH_ACTIVE": "0"},
-    "host_block_relabel": {"GGC_MF_ASYNC_RELAX": "0", "GGC_MF_ASYNC_PUSH_ACTIVE": "0", "GGC_MF_RELAX_WAVE": "1"},
     "async_default": {},
-    "async_all_push_rounds": {"GGC_MF_ASYNC_PUSH_ACTIVE": "100000000", "GGC_MF_RELAX_DENSE": "0"},
-    "async_tiles_32x16": {"GGC_MF_ASYNC_TH": "16", "GGC_MF_ASYNC_INNER": "16"},
-    "async_tiles_32x32_no_follow": {"GGC_MF_ASYNC_TH": "32", "GGC_MF_ASYNC_FOLLOW": "0", "GGC_MF_ASYNC_GEN": "8"},
-    "wave_per_tile_dense_push": {"GGC_MF_PR_WAVE": "1"},
-    "pixel_relabel_start": {"GGC_MF_TILE_INIT": "0"},
-    "image_driver": {"GGC_MF_DRIVER": "image"},
-    "pool_driver": {"GGC_MF_DRIVER": "pool"},
-    "hybrid_driver": {"GGC_MF_DRIVER": "hybrid"},
+    "host_work_lists": {"GGC_MF_ASYNC": "0"},
+    "cold_start_every_iteration": {"GGC_MF_WARM": "0"},
+    "async_all_push_rounds": {"GGC_MF_ASYNC_PUSH_ACTIVE": "100000000", "GGC_MF_RELAX_DENSE": "1"},
+    "async_tiles_32x16": {"GGC_MF_ASYNC_TILE": "16", "GGC_MF_ASYNC_SWEEPS": "16"},
+    "async_tiles_32x32_short_chains": {"GGC_MF_ASYNC_TILE": "32", "GGC_MF_ASYNC_HOPS": "8"},
+    "short_dense_rounds": {"GGC_MF_DENSE_LAUNCHES0": "3", "GGC_MF_DENSE_LAUNCHES": "2", "GGC_MF_DENSE_SWEEPS": "4", "GGC_MF_RELAX_DENSE": "4"},
 }
 
 

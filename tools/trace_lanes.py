@@ -10,7 +10,8 @@ for r in rows:
 ev.sort()
 # steps: find k_preprocess launches (one per step)
 pre = [e[0] for e in ev if "k_preprocess" in e[2]]
-t0 = pre[-1]
+import os
+t0 = pre[-int(os.environ.get("NPRE", "1"))]      # NPRE: k_preprocess launches per step (chunks of the software pipeline)
 t1 = ev[-1][1]
 step = [e for e in ev if e[0] >= t0]
 print(f"last step: {len(step)} kernels, span {(t1 - t0) / 1e6:.2f} ms")
@@ -19,6 +20,15 @@ for e in step: byq[(e[3], e[4])].append(e)
 for q, l in sorted(byq.items()):
     busy = sum(e[1] - e[0] for e in l)
     print(f"queue/stream {q}: {len(l):5d} kernels, busy {busy / 1e6:7.2f} ms, span {(l[-1][1] - l[0][0]) / 1e6:7.2f} ms, first at +{(l[0][0] - t0) / 1e6:.2f} ms")
+# busy fraction per queue in 5-ms bins
+nb = int((t1 - t0) / 5e6) + 1
+for q, l in sorted(byq.items()):
+    bins = [0.0] * nb
+    for e in l:
+        a, b_ = e[0] - t0, e[1] - t0
+        for k in range(int(a / 5e6), min(nb - 1, int(b_ / 5e6)) + 1):
+            bins[k] += max(0.0, min(b_, (k + 1) * 5e6) - max(a, k * 5e6))
+    print(f"  busy % per 5 ms, queue {q}: " + " ".join(f"{100 * v / 5e6:3.0f}" for v in bins))
 # union busy + concurrency
 pts = []
 for e in step: pts.append((e[0], 1)); pts.append((e[1], -1))
