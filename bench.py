@@ -156,6 +156,9 @@ def main() -> None:
     ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the all-cores leg (default: the cores this "
                     "process may use, at most 16 = one GPU's share of the host)")
     ap.add_argument("--h2d-steps", type=int, default=3, help="extra timed steps that include the host->device copy of the batch (0 = skip)")
+    ap.add_argument("--force-collective", action="store_true", help="initialise the RCCL process group, the barriers, the MAX "
+                    "all-reduce of the step time and the gather of the per-rank records even when WORLD_SIZE is 1 (warms the "
+                    "N > 1 path on a one-GPU box; under torch.distributed.run --nproc-per-node 1 or on its own)")
     args = ap.parse_args()
     batch_size = args.batch or (256 if args.workload == "full" else 64)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -169,10 +172,16 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective          # everything below that talks to other ranks hangs off this
+    if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; gathers timings only
+        if "MASTER_PORT" not in os.environ:                  # --force-collective without a launcher: a job of one rank
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI; gathers timings only
 
     from gcn_grabcut import _native
     from gcn_grabcut.data import Batch, Data
@@ -188,8 +197,12 @@ def main() -> None:
 
     host_imgs = host_graphs = None
     if args.workload == "full":
-        # this rank's shard: images rank*B .. rank*B + B - 1 of config 3 (seeds 30000 + index)
-        host_imgs = synthetic_batch(batch_size, H, W, config_id=3, first_index=rank * batch_size)
+        # this rank's shard of the job's world * B images of config 3 (seeds 30000 + index): the contiguous block the
+        # product's sharding rule gives it (gcn_grabcut/distributed.py, the rule tests/test_distributed_cpu.py checks)
+        from gcn_grabcut.distributed import shard_range
+        shard = shard_range(batch_size * world, rank, world)
+        assert len(shard) == batch_size
+        host_imgs = synthetic_batch(batch_size, H, W, config_id=3, first_index=shard.start)
         n_pipes = max(1, args.pipelines)
         lanes = args.lanes if args.lanes > 0 else (4 if n_pipes == 1 else 1)
         pipe = GCNGrabCutPipeline(model, sp_config=SuperpixelGraphConfig(n_segments=N_SEGMENTS), device=f"cuda:{local_rank}",
@@ -250,7 +263,7 @@ def main() -> None:
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -275,7 +288,7 @@ def main() -> None:
         c.profile_enable(False)
 
     elapsed_rank = elapsed
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -290,7 +303,7 @@ def main() -> None:
             last["out"] = pipe.segment_batch_device(pinned.to(dev, non_blocking=True), compose=True)
         sync_all()
         e1 = time.perf_counter() - t1
-        if world > 1:
+        if collective:
             t = torch.tensor([e1], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e1 = float(t.item())
@@ -408,7 +421,7 @@ def main() -> None:
                 cpu.update(value=cpu["all_cores"]["value"], cores=workers,
                            sample=f"{n_all} images, full pipeline, C oracle on {workers} worker processes (host has {host_cores} cores); "
                                   f"single thread: {single['value']} images/s")
-    records = gather_records(rec, dev if world > 1 else None)      # the path's only collective: 64 bytes per rank
+    records = gather_records(rec, dev if collective else None)      # the path's only collective: 64 bytes per rank
 
     if rank == 0:
         if args.workload == "full":
@@ -486,10 +499,10 @@ def main() -> None:
                        "inputs": "uint8 batch resident in HBM when the clock starts (h2d_inclusive has the copy inside)"},
             "roofline": roofline, "pipeline_roofline": pipeline_roofline, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity,
             "stage_ms_per_step": stage_ms, "stages": stage_table, "trimap_label_fractions": trimap_hist,
-            "h2d_inclusive": h2d, "ranks": job["per_rank"] if world > 1 else None, "overlapped": overlapped,
+            "h2d_inclusive": h2d, "ranks": job["per_rank"] if collective else None, "overlapped": overlapped,
         }
         print(json.dumps(out_json), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

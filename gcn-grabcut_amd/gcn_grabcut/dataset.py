@@ -174,33 +174,34 @@ def _hsv8_to_bgr(hsv: np.ndarray) -> np.ndarray:
     return np.clip(np.rint(np.stack([b, g, r], -1)), 0, 255).astype(np.uint8)
 
 
-def _color_jitter(image: np.ndarray) -> np.ndarray:
+def _color_jitter(image: np.ndarray, rng=random) -> np.ndarray:
     """reference dataset.py:154-168 (three draws: brightness, contrast, saturation)"""
     img = image.astype(np.float32)
-    img = np.clip(img + np.float32(random.uniform(-40, 40)), 0, 255)
-    img = np.clip(np.float32(128) + np.float32(random.uniform(0.7, 1.3)) * (img - np.float32(128)), 0, 255)
+    img = np.clip(img + np.float32(rng.uniform(-40, 40)), 0, 255)
+    img = np.clip(np.float32(128) + np.float32(rng.uniform(0.7, 1.3)) * (img - np.float32(128)), 0, 255)
     hsv = _bgr_to_hsv8(img.astype(np.uint8)).astype(np.float32)
-    hsv[:, :, 1] = np.clip(hsv[:, :, 1] * np.float32(random.uniform(0.7, 1.3)), 0, 255)
+    hsv[:, :, 1] = np.clip(hsv[:, :, 1] * np.float32(rng.uniform(0.7, 1.3)), 0, 255)
     return _hsv8_to_bgr(hsv.astype(np.uint8))
 
 
 def augment_sample(image: np.ndarray, mask: np.ndarray, prob_flip: float = 0.5, prob_rotate: float = 0.3,
-                   prob_color: float = 0.5, prob_crop: float = 0.3):
-    """Stochastic augmentation of an image / mask pair — reference dataset.py:107-151; draws from `random` in its order."""
+                   prob_color: float = 0.5, prob_crop: float = 0.3, rng=random):
+    """Stochastic augmentation of an image / mask pair — reference dataset.py:107-151; draws in its order from `rng`
+    (the `random` module like the reference, or a private random.Random — same Mersenne stream, no global state)."""
     h, w = image.shape[:2]
-    if random.random() < prob_flip:
+    if rng.random() < prob_flip:
         image, mask = image[:, ::-1], mask[:, ::-1]
-    if random.random() < prob_rotate:
-        m = _rotation_matrix(w / 2, h / 2, random.uniform(-15, 15))
+    if rng.random() < prob_rotate:
+        m = _rotation_matrix(w / 2, h / 2, rng.uniform(-15, 15))
         image = _warp_affine(image, m, linear=True)
         mask = _warp_affine(mask.astype(np.uint8), m, linear=False)
-    if random.random() < prob_color:
-        image = _color_jitter(image)
-    if random.random() < prob_crop:
-        scale = random.uniform(0.75, 1.0)
+    if rng.random() < prob_color:
+        image = _color_jitter(image, rng)
+    if rng.random() < prob_crop:
+        scale = rng.uniform(0.75, 1.0)
         ch, cw = int(h * scale), int(w * scale)
-        y0 = random.randint(0, h - ch)
-        x0 = random.randint(0, w - cw)
+        y0 = rng.randint(0, h - ch)
+        x0 = rng.randint(0, w - cw)
         image = _resize_bilinear_u8(image[y0:y0 + ch, x0:x0 + cw], h, w)
         mask = _resize_nearest(mask[y0:y0 + ch, x0:x0 + cw], h, w)
     return np.ascontiguousarray(image), np.ascontiguousarray(mask)
@@ -226,12 +227,11 @@ def materialise(sample: dict) -> Optional[dict]:
     image, mask = _resize_pair(image, mask, sample.get("max_size", 512))
     gt_mask = (mask > 127).astype(np.uint8)
     if sample.get("aug_seed") is not None:                 # seeded: the copy is the same every run (dataset.py:343-353)
-        state = random.getstate()
-        random.seed(sample["aug_seed"])
-        try:
-            image, gt_mask = augment_sample(image, gt_mask, prob_flip=0.5, prob_rotate=0.4, prob_color=0.6, prob_crop=0.4)
-        finally:
-            random.setstate(state)
+        # The reference seeds the process-global `random` inside a worker PROCESS; prepare_dataset decodes on worker THREADS,
+        # which would interleave their draws on one global generator.  A private random.Random(seed) is the same Mersenne
+        # stream as random.seed(seed), so a seed still gives the reference's parameter sequence — on any thread.
+        image, gt_mask = augment_sample(image, gt_mask, prob_flip=0.5, prob_rotate=0.4, prob_color=0.6, prob_crop=0.4,
+                                        rng=random.Random(sample["aug_seed"]))
     if gt_mask.sum() < 200 or (1 - gt_mask).sum() < 200:
         return None
     return {"image": np.ascontiguousarray(image), "gt_mask": np.ascontiguousarray(gt_mask), "name": sample.get("name", "")}

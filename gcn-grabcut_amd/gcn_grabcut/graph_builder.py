@@ -138,19 +138,34 @@ def compute_auto_prior(segments: np.ndarray, lab: np.ndarray, centre_sigma: floa
                        contrast_sigma: float = 0.40, device="cuda") -> np.ndarray:
     """(N, 3) float32 [fg-ness, bg-ness, ambiguity] — reference graph_builder.py:357-444."""
     import torch
-    from ._engine import get_engine
+    from ._engine import Engine, get_engine
     eng = get_engine(device)
+    custom = (float(centre_sigma), float(contrast_sigma)) != (0.45, 0.40)
+    if custom:
+        # The sigmas are state of a library context.  Non-default values go to a PRIVATE context (one per device, serialised
+        # by a lock), so the shared context — which other threads build the pipeline's graphs with — never leaves the defaults.
+        with _prior_lock:
+            peng = _prior_engines.get(eng.index)
+            if peng is None:
+                peng = _prior_engines[eng.index] = Engine(eng.index, private_context=True)
+            peng.ctx.call("ggc_graph_prior_sigmas", float(centre_sigma), float(contrast_sigma))
+            return _auto_prior_on(peng, segments, lab)
+    return _auto_prior_on(eng, segments, lab)
+
+
+_prior_engines: dict = {}
+_prior_lock = __import__("threading").Lock()
+
+
+def _auto_prior_on(eng, segments: np.ndarray, lab: np.ndarray) -> np.ndarray:
+    import torch
     seg = eng.to_device(np.ascontiguousarray(segments, dtype=np.int32)[None])
     lab_d = eng.to_device(np.ascontiguousarray(lab, dtype=np.float32)[None])
     h, w = segments.shape
     n = torch.tensor([int(segments.max()) + 1], dtype=torch.int32, device=eng.device)
     zeros3 = torch.zeros(1, h, w, 3, device=eng.device)
     zeros1 = torch.zeros(1, h, w, device=eng.device)
-    eng.ctx.call("ggc_graph_prior_sigmas", float(centre_sigma), float(contrast_sigma))
-    try:
-        graphs = eng.build_graphs(seg, n, lab_d, zeros3, zeros1, 4, 0)
-    finally:
-        eng.ctx.call("ggc_graph_prior_sigmas", 0.45, 0.40)     # the pipeline's graphs use the reference defaults
+    graphs = eng.build_graphs(seg, n, lab_d, zeros3, zeros1, 4, 0)
     return graphs.x[:, N_IMAGE_FEATS:].cpu().numpy()
 
 

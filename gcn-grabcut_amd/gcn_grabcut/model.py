@@ -472,9 +472,15 @@ if _TORCH:
             ctx.call("ggc_gat_ready")
             ctx.resident["gat"] = fp
 
-        def _run(self, data, want_logits: bool, want_probs: bool, ctx=None):
+        def _run(self, data, want_logits: bool, want_probs: bool, ctx=None, check_loops: bool = True):
             if self.training:
                 raise RuntimeError("GATTrimapNet on MI355X is inference-only: call .eval() first")
+            # PyG's GATv2Conv(add_self_loops=True) REMOVES i -> i edges (and their attributes) before it adds its own
+            # mean-filled loops; the kernels keep every input edge.  GraphBuilder never emits a loop, so the pipeline is
+            # unaffected; a user-supplied edge_index that holds one is refused rather than answered differently.
+            if check_loops and data.edge_index.numel() and bool((data.edge_index[0] == data.edge_index[1]).any()):
+                raise ValueError("GATTrimapNet: edge_index holds self-loops (i -> i); PyG's GATv2Conv drops them before adding "
+                                 "its own, which this build does not do — remove them (edge_attr rows included) first")
             dev_index = self._device_index()
             if ctx is None:
                 ctx = _native.get_context(dev_index)
@@ -513,9 +519,10 @@ if _TORCH:
 
         @torch.no_grad()
         def predict_probs_device(self, data, ctx=None) -> "torch.Tensor":
+            """the pipeline's entry: graphs straight from the graph stage (no loops by construction, no host sync to check)"""
             if self.training:
                 self.eval()
-            return self._run(data, False, True, ctx)[1]
+            return self._run(data, False, True, ctx, check_loops=False)[1]
 
         @torch.no_grad()
         def predict_trimap(self, data, segments: np.ndarray, threshold_fg: float = 0.55, threshold_bg: float = 0.55) -> np.ndarray:

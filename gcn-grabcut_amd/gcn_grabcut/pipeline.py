@@ -110,13 +110,17 @@ def eroded_box(H: int, W: int, bbox: tuple[int, int, int, int], ksize: int = 30)
     border counts pixels OUTSIDE the image as set, so a side of the box that lies on the image edge is not eroded."""
     x, y, w, h = bbox
     a, b = ksize // 2, ksize - 1 - ksize // 2
-    by0, by1, bx0, bx1 = max(y, 0), min(y + h, H), max(x, 0), min(x + w, W)
+    # the reference fills `inner[y:y+h, x:x+w] = 1` (pipeline.py:368): numpy slice semantics, so a negative start counts from
+    # the far edge (and usually selects nothing) and a stop past the frame is cut — the same rows and columns the
+    # FG_PROBABLE write of segment_bbox gets
+    by0, by1, _ = slice(y, y + h).indices(H)
+    bx0, bx1, _ = slice(x, x + w).indices(W)
+    if by1 <= by0 or bx1 <= bx0:
+        return 0, 0, 0, 0
     y0 = by0 if by0 == 0 else by0 + a
     y1 = by1 if by1 == H else by1 - b
     x0 = bx0 if bx0 == 0 else bx0 + a
     x1 = bx1 if bx1 == W else bx1 - b
-    if by1 <= by0 or bx1 <= bx0:
-        return 0, 0, 0, 0
     return y0, y1, x0, x1
 
 

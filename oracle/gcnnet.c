@@ -41,6 +41,40 @@ static void linear_row(const float* x, const float* W, const float* b, int in, i
     }
 }
 
+/* EdgeInjectionLayer gates (model.py:159-162): per destination, the SUM over its incoming edges of
+ * sigmoid(W2 relu(W1 a + b1) + b2) and the edge count (the caller divides: _scatter_mean :69-74).
+ * Q[0..3] = proj.0.weight[D,5] proj.0.bias proj.2.weight[D,D] proj.2.bias; buf: >= 2 D floats. */
+static void edge_injection_gates(int N, int E, int D, const float* const* Q, const float* edge_attr, const int64_t* dst,
+                                 float* gates, float* cnt, float* buf) {
+    memset(gates, 0, (size_t)N * D * sizeof(float));
+    memset(cnt, 0, (size_t)N * sizeof(float));
+    float* e1 = buf; float* e2 = buf + D;
+    for (int e = 0; e < E; ++e) {
+        linear_row(edge_attr + (size_t)e * EDGE_CH, Q[0], Q[1], EDGE_CH, D, e1);
+        for (int k = 0; k < D; ++k) e1[k] = e1[k] > 0.0f ? e1[k] : 0.0f;
+        linear_row(e1, Q[2], Q[3], D, D, e2);
+        float* gr = gates + (size_t)dst[e] * D;
+        for (int k = 0; k < D; ++k) gr[k] += ggc_sigmoid_nr(e2[k]);        /* the kernel's form (include/ggc_fmath.h) */
+        cnt[dst[e]] += 1.0f;
+    }
+}
+
+/* EdgeInjectionLayer.forward on its own (model.py:157-162), for the fixtures recorded from the reference's module */
+int ggo_edge_injection(const float* const* Q, int D, int N, int E, const float* edge_attr, const int64_t* edge_index,
+                       const float* node_updates, float* out) {
+    float* gates = (float*)malloc((size_t)N * D * sizeof(float));
+    float* cnt = (float*)malloc((size_t)N * sizeof(float));
+    float* buf = (float*)malloc((size_t)(2 * D + 64) * sizeof(float));
+    if (!gates || !cnt || !buf) return -1;
+    edge_injection_gates(N, E, D, Q, edge_attr, edge_index + E, gates, cnt, buf);
+    for (int i = 0; i < N; ++i) {
+        const float c = cnt[i] > 1.0f ? cnt[i] : 1.0f;
+        for (int k = 0; k < D; ++k) out[(size_t)i * D + k] = node_updates[(size_t)i * D + k] * (gates[(size_t)i * D + k] / c);
+    }
+    free(gates); free(cnt); free(buf);
+    return 0;
+}
+
 int ggo_gcnnet_forward(const float* const* P, int D, int n_layers, int N, int E, const float* x, const int64_t* edge_index,
                        const float* edge_attr, float* logits, float* probs) {
     const int Dh = D / 2, n_states = n_layers + 1;
@@ -71,18 +105,7 @@ int ggo_gcnnet_forward(const float* const* P, int D, int n_layers, int N, int E,
         float* out = states + ND * (l + 1);
         for (int i = 0; i < N; ++i) linear_row(h + (size_t)i * D, B[1], NULL, D, D, xw + (size_t)i * D);
         ggo_gcn_aggregate(N, E, D, xw, edge_index, B[0], NULL, NULL, conv);
-        /* edge injection gates: scatter-mean over dst of sigmoid(W2 relu(W1 a + b1) + b2) — :159-162, _scatter_mean :69-74 */
-        memset(gates, 0, ND * sizeof(float));
-        memset(cnt, 0, (size_t)N * sizeof(float));
-        float* e1 = buf; float* e2 = buf + D;
-        for (int e = 0; e < E; ++e) {
-            linear_row(edge_attr + (size_t)e * EDGE_CH, B[6], B[7], EDGE_CH, D, e1);
-            for (int k = 0; k < D; ++k) e1[k] = e1[k] > 0.0f ? e1[k] : 0.0f;
-            linear_row(e1, B[8], B[9], D, D, e2);
-            float* gr = gates + (size_t)dst[e] * D;
-            for (int k = 0; k < D; ++k) gr[k] += ggc_sigmoid_nr(e2[k]);        /* the kernel's form (include/ggc_fmath.h) */
-            cnt[dst[e]] += 1.0f;
-        }
+        edge_injection_gates(N, E, D, B + 6, edge_attr, dst, gates, cnt, buf);
         for (int i = 0; i < N; ++i) {
             const float c = cnt[i] > 1.0f ? cnt[i] : 1.0f;
             for (int k = 0; k < D; ++k) {

@@ -80,6 +80,14 @@ void ggo_auto_prior_sigmas(int H, int W, const int32_t* segments, const float* l
 
 /* ---- M0-M7: ResGCNNet.forward (model.py:508-536), eval mode ---- */
 int ggo_resgcn_n_params(int n_layers);
+/* network blocks on their own (what the forwards above call), for fixtures recorded from the reference's modules:
+ * InputNorm eval (model.py:191-213), EdgeContext (:111-139), GlobalContextModule + _graph_softmax (:90-108,165-188),
+ * EdgeInjectionLayer (:142-162).  Q = the module's parameters in state_dict order. */
+void ggo_input_norm(int N, const float* x, const float* w, const float* b, const float* mean, const float* var, float* out);
+int ggo_edge_context(const float* const* Q, int D, int N, int E, const float* edge_attr, const int64_t* edge_index, float* gate);
+int ggo_global_context(const float* const* Q, int D, int N, const float* h, const int64_t* batch, int n_graphs, float* out, float* weights);
+int ggo_edge_injection(const float* const* Q, int D, int N, int E, const float* edge_attr, const int64_t* edge_index,
+                       const float* node_updates, float* out);
 /* GCNTrimapNet.forward, eval mode (reference model.py:239-316); parameter order in oracle/gcnnet.c */
 int ggo_gcnnet_n_params(int n_layers);
 int ggo_gcnnet_forward(const float* const* params, int D, int n_layers, int N, int E, const float* x,

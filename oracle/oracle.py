@@ -84,6 +84,54 @@ def resgcn_forward(state: dict, hidden: int, n_layers: int, x, edge_index, edge_
     return logits, probs
 
 
+def _ptr_array(arrs):
+    return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def input_norm(x, weight, bias, running_mean, running_var):
+    """InputNorm in eval mode (reference model.py:191-213) -> (N,19) float32."""
+    x = f32(x)
+    out = np.empty_like(x)
+    w, b, m, v = f32(weight), f32(bias), f32(running_mean), f32(running_var)
+    lib().ggo_input_norm(_i(x.shape[0]), _p(x), _p(w), _p(b), _p(m), _p(v), _p(out))
+    return out
+
+
+def edge_context(state: dict, hidden: int, edge_attr, edge_index, n_nodes: int, prefix: str = ""):
+    """EdgeContext.forward (reference model.py:111-139) -> gate (N,D).  state: the module's state_dict as arrays."""
+    keys = ["encode.0.weight", "encode.0.bias", "encode.2.weight", "encode.2.bias",
+            "to_gate.0.weight", "to_gate.0.bias", "to_gate.1.weight", "to_gate.1.bias"]
+    arrs = [f32(np.asarray(state[prefix + k])) for k in keys]
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    ea = f32(edge_attr)
+    gate = np.empty((n_nodes, hidden), np.float32)
+    assert lib().ggo_edge_context(_ptr_array(arrs), _i(hidden), _i(n_nodes), _i(ei.shape[1]), _p(ea), _p(ei), _p(gate)) == 0
+    return gate
+
+
+def global_context(state: dict, hidden: int, h, batch=None, prefix: str = ""):
+    """GlobalContextModule.forward (reference model.py:165-188) -> (h * g (N,D), per-graph softmax weights (N,))."""
+    keys = ["attn.weight", "attn.bias", "compress.weight", "compress.bias", "expand.weight", "expand.bias"]
+    arrs = [f32(np.asarray(state[prefix + k])) for k in keys]
+    h = f32(h)
+    b = None if batch is None else np.ascontiguousarray(batch, dtype=np.int64)
+    ng = 1 if b is None else int(b.max()) + 1
+    out, w = np.empty_like(h), np.empty(h.shape[0], np.float32)
+    assert lib().ggo_global_context(_ptr_array(arrs), _i(hidden), _i(h.shape[0]), _p(h), _p(b), _i(ng), _p(out), _p(w)) == 0
+    return out, w
+
+
+def edge_injection(state: dict, hidden: int, edge_attr, edge_index, node_updates, prefix: str = ""):
+    """EdgeInjectionLayer.forward (reference model.py:142-162) -> node_updates * scatter_mean(gates)."""
+    keys = ["proj.0.weight", "proj.0.bias", "proj.2.weight", "proj.2.bias"]
+    arrs = [f32(np.asarray(state[prefix + k])) for k in keys]
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    ea, nu = f32(edge_attr), f32(node_updates)
+    out = np.empty_like(nu)
+    assert lib().ggo_edge_injection(_ptr_array(arrs), _i(hidden), _i(nu.shape[0]), _i(ei.shape[1]), _p(ea), _p(ei), _p(nu), _p(out)) == 0
+    return out
+
+
 def gcnnet_param_order(n_layers: int) -> list[str]:
     """GCNTrimapNet state_dict keys in the order oracle/gcnnet.c expects."""
     bn = ("weight", "bias", "running_mean", "running_var")

@@ -172,13 +172,139 @@ void ggo_gcn_conv(int N, int E, int D, const float* x, const int64_t* edge_index
     free(xw);
 }
 
+/* InputNorm in eval mode (model.py:191-213): BatchNorm1d with the stored statistics, one row */
+static void input_norm_row(const float* xi, const float* w, const float* b, const float* mean, const float* var, float* xn) {
+    for (int k = 0; k < IN_CH; ++k) xn[k] = (xi[k] - mean[k]) / sqrtf(var[k] + 1e-5f) * w[k] + b[k];
+}
+
+/* EdgeContext.forward (model.py:135-139): per-edge MLP, scatter-mean over dst (_scatter_mean :69-74), to_gate.   [k_edge_gate]
+ * Q[0..7] = encode.0.weight[C,5] encode.0.bias encode.2.weight[C,C] encode.2.bias to_gate.0.weight[C] to_gate.0.bias
+ * to_gate.1.weight[D,C] to_gate.1.bias.  rowbuf: >= 4 max(C, D) floats.
+ * The mean over a node's incoming edges commutes with the second (linear) layer: mean_e(W2 e1 + b2) = W2 mean_e(e1) + b2;
+ * a node without incoming edges gets the zero vector (_scatter_mean :69-74). */
+static void edge_context(int N, int E, int D, int C, const float* const* Q, const float* edge_attr, const int64_t* dst,
+                         float* gate, float* rowbuf) {
+    float* e1sum = (float*)calloc((size_t)N * C, sizeof(float));
+    int* cnt = (int*)calloc((size_t)N, sizeof(int));
+    float* e1 = rowbuf;
+    for (int e = 0; e < E; ++e) {                      /* edge order == CSR order per destination */
+        linear_row(edge_attr + (size_t)e * EDGE_CH, Q[0], Q[1], EDGE_CH, C, e1);
+        float* o = e1sum + (size_t)dst[e] * C;
+        for (int k = 0; k < C; ++k) o[k] += gelu_f(e1[k]);
+        cnt[dst[e]] += 1;
+    }
+    float* m = rowbuf;
+    float* cv = rowbuf + C;
+    float* ln = rowbuf + 2 * C;
+    float* gt = rowbuf + 3 * C;
+    for (int i = 0; i < N; ++i) {
+        const float c = (float)(cnt[i] > 0 ? cnt[i] : 1);
+        for (int k = 0; k < C; ++k) m[k] = e1sum[(size_t)i * C + k] / c;
+        if (cnt[i] > 0) linear_row(m, Q[2], Q[3], C, C, cv);
+        else for (int k = 0; k < C; ++k) cv[k] = 0.0f;
+        float mean, rstd;
+        {   /* lanes >= C hold zeros in the kernel's wave sums */
+            float v[64];
+            for (int l = 0; l < 64; ++l) v[l] = l < C ? cv[l] : 0.0f;
+            mean = butterfly(v, 64) / (float)C;
+            for (int l = 0; l < 64; ++l) { const float d = l < C ? cv[l] - mean : 0.0f; v[l] = d * d; }
+            rstd = 1.0f / sqrtf(butterfly(v, 64) / (float)C + 1e-5f);
+        }
+        for (int k = 0; k < C; ++k) ln[k] = (cv[k] - mean) * rstd * Q[4][k] + Q[5][k];
+        linear_row(ln, Q[6], NULL, C, D, gt);
+        for (int k = 0; k < D; ++k) gate[(size_t)i * D + k] = sigmoid_f(gt[k] + Q[7][k]);
+    }
+    free(e1sum); free(cnt);
+}
+
+/* GlobalContextModule.forward (model.py:176-188) with _graph_softmax (:90-108): out = h * sigmoid(expand(relu(compress(
+ * sum_i softmax_i(attn(h)) h_i)))) per graph.   [k_jk's score + k_graph_ctx]
+ * Q[0..5] = attn.weight[1,D] attn.bias[1] compress.weight[D/2,D] compress.bias expand.weight[D,D/2] expand.bias.
+ * rowbuf: >= 3 D floats.  weights_out (optional, [N]): the per-graph softmax of the attention scores. */
+static void global_context(int N, int D, const float* h, const int64_t* batch, int n_graphs, const float* const* Q,
+                           float* out, float* rowbuf, float* weights_out) {
+    const int Dh = D / 2;
+    const float* aw = Q[0];
+    const float* ab = Q[1];
+    const int Dp = padded_width(D);                                /* the kernels' width: channels >= D are zeros */
+    const int LPR = Dp <= 32 ? 8 : (Dp <= 64 ? 16 : 32);          /* lanes per row, 4 consecutive channels each */
+    float* score = (float*)malloc((size_t)N * sizeof(float));
+    for (int i = 0; i < N; ++i) {
+        float v[32];
+        const float* hr = h + (size_t)i * D;
+        for (int l = 0; l < LPR; ++l) {
+            float p[4];
+            for (int u = 0; u < 4; ++u) p[u] = 4 * l + u < D ? hr[4 * l + u] * aw[4 * l + u] : 0.0f;
+            v[l] = ((p[0] + p[1]) + p[2]) + p[3];
+        }
+        score[i] = butterfly(v, LPR) + ab[0];
+    }
+    /* graphs are contiguous node ranges (PyG Batch); one 256-thread block per graph */
+    const int NG = 256 / Dp;
+    float* gs = (float*)malloc((size_t)n_graphs * D * sizeof(float));
+    int beg = 0;
+    for (int q = 0; q < n_graphs; ++q) {
+        int end = beg;
+        if (batch) { while (end < N && (int)batch[end] == q) ++end; } else end = N;
+        float peak = -INFINITY;
+        for (int i = beg; i < end; ++i) if (score[i] > peak) peak = score[i];
+        float red[256];
+        for (int t = 0; t < 256; ++t) { float sacc = 0.0f; for (int i = beg + t; i < end; i += 256) sacc += ggc_expf(score[i] - peak); red[t] = sacc; }
+        for (int o = 128; o > 0; o >>= 1) for (int t = 0; t < o; ++t) red[t] += red[t + o];
+        const float tot = red[0] + 1e-12f;             /* model.py:108 (absorbed in float32 for any non-empty graph) */
+        if (weights_out) for (int i = beg; i < end; ++i) weights_out[i] = ggc_expf(score[i] - peak) / tot;
+        float* g = rowbuf;                             /* weighted sum: NG strided groups per channel, then added in group order */
+        for (int k = 0; k < D; ++k) {
+            float v = 0.0f;
+            for (int grp = 0; grp < NG; ++grp) {
+                float acc = 0.0f;
+                for (int i = beg + grp; i < end; i += NG) acc += (ggc_expf(score[i] - peak) / tot) * h[(size_t)i * D + k];
+                v += acc;
+            }
+            g[k] = v;
+        }
+        float* c = rowbuf + D;
+        linear_row(g, Q[2], Q[3], D, Dh, c);
+        for (int k = 0; k < Dh; ++k) c[k] = c[k] > 0.0f ? c[k] : 0.0f;
+        float* ex = rowbuf + 2 * D;
+        linear_row(c, Q[4], NULL, Dh, D, ex);
+        for (int k = 0; k < D; ++k) gs[(size_t)q * D + k] = sigmoid_f(ex[k] + Q[5][k]);
+        beg = end;
+    }
+    for (int i = 0; i < N; ++i) {
+        int q = batch ? (int)batch[i] : 0;
+        for (int k = 0; k < D; ++k) out[(size_t)i * D + k] = h[(size_t)i * D + k] * gs[(size_t)q * D + k];
+    }
+    free(score); free(gs);
+}
+
+/* The three blocks on their own, for the fixtures recorded from the reference's modules (tests/golden/reference_modules.npz) */
+void ggo_input_norm(int N, const float* x, const float* w, const float* b, const float* mean, const float* var, float* out) {
+    for (int i = 0; i < N; ++i) input_norm_row(x + (size_t)i * IN_CH, w, b, mean, var, out + (size_t)i * IN_CH);
+}
+int ggo_edge_context(const float* const* Q, int D, int N, int E, const float* edge_attr, const int64_t* edge_index, float* gate) {
+    const int C = (D / 2 > 8) ? D / 2 : 8;
+    float* rowbuf = (float*)malloc((size_t)(4 * (C > D ? C : D) + 64) * sizeof(float));
+    if (!rowbuf) return -1;
+    edge_context(N, E, D, C, Q, edge_attr, edge_index + E, gate, rowbuf);
+    free(rowbuf);
+    return 0;
+}
+int ggo_global_context(const float* const* Q, int D, int N, const float* h, const int64_t* batch, int n_graphs, float* out, float* weights) {
+    float* rowbuf = (float*)malloc((size_t)(4 * D + 64) * sizeof(float));
+    if (!rowbuf) return -1;
+    if (!batch) n_graphs = 1;
+    global_context(N, D, h, batch, n_graphs, Q, out, rowbuf, weights);
+    free(rowbuf);
+    return 0;
+}
+
 int ggo_resgcn_forward(const float* const* P, int D, int n_layers,
                        int N, int E, const float* x, const int64_t* edge_index,
                        const float* edge_attr, const int64_t* batch, int n_graphs,
                        float* logits, float* probs) {
     const int Q = (D / 4 > 8) ? D / 4 : 8;
     const int C = (D / 2 > 8) ? D / 2 : 8;
-    const int Dh = D / 2;
     const int64_t* src = edge_index;
     const int64_t* dst = edge_index + E;
     if (!batch) n_graphs = 1;
@@ -196,8 +322,7 @@ int ggo_resgcn_forward(const float* const* P, int D, int n_layers,
     for (int i = 0; i < N; ++i) {
         const float* xi = x + (size_t)i * IN_CH;
         float xn[IN_CH];
-        for (int k = 0; k < IN_CH; ++k)
-            xn[k] = (xi[k] - P[2][k]) / sqrtf(P[3][k] + 1e-5f) * P[0][k] + P[1][k];
+        input_norm_row(xi, P[0], P[1], P[2], P[3], xn);
         float* a = rowbuf;
         float* bq = rowbuf + D;
         linear_row(xn, P[4], P[5], IN_CH, D, a);
@@ -214,42 +339,8 @@ int ggo_resgcn_forward(const float* const* P, int D, int n_layers,
         }
     }
 
-    /* ---- EdgeContext (model.py:135-139): per-edge MLP, scatter-mean over dst, to_gate   [k_edge_gate]
-     * The mean over a node's incoming edges commutes with the second (linear) layer: mean_e(W2 e1 + b2) = W2 mean_e(e1) + b2;
-     * a node without incoming edges gets the zero vector (_scatter_mean :69-74). */
-    {
-        float* e1sum = (float*)calloc((size_t)N * C, sizeof(float));
-        int* cnt = (int*)calloc((size_t)N, sizeof(int));
-        float* e1 = rowbuf;
-        for (int e = 0; e < E; ++e) {                      /* edge order == CSR order per destination */
-            linear_row(edge_attr + (size_t)e * EDGE_CH, P[12], P[13], EDGE_CH, C, e1);
-            float* o = e1sum + (size_t)dst[e] * C;
-            for (int k = 0; k < C; ++k) o[k] += gelu_f(e1[k]);
-            cnt[dst[e]] += 1;
-        }
-        float* m = rowbuf;
-        float* cv = rowbuf + C;
-        float* ln = rowbuf + 2 * C;
-        float* gt = rowbuf + 3 * C;
-        for (int i = 0; i < N; ++i) {
-            const float c = (float)(cnt[i] > 0 ? cnt[i] : 1);
-            for (int k = 0; k < C; ++k) m[k] = e1sum[(size_t)i * C + k] / c;
-            if (cnt[i] > 0) linear_row(m, P[14], P[15], C, C, cv);
-            else for (int k = 0; k < C; ++k) cv[k] = 0.0f;
-            float mean, rstd;
-            {   /* lanes >= C hold zeros in the kernel's wave sums */
-                float v[64];
-                for (int l = 0; l < 64; ++l) v[l] = l < C ? cv[l] : 0.0f;
-                mean = butterfly(v, 64) / (float)C;
-                for (int l = 0; l < 64; ++l) { const float d = l < C ? cv[l] - mean : 0.0f; v[l] = d * d; }
-                rstd = 1.0f / sqrtf(butterfly(v, 64) / (float)C + 1e-5f);
-            }
-            for (int k = 0; k < C; ++k) ln[k] = (cv[k] - mean) * rstd * P[16][k] + P[17][k];
-            linear_row(ln, P[18], NULL, C, D, gt);
-            for (int k = 0; k < D; ++k) gate[(size_t)i * D + k] = sigmoid_f(gt[k] + P[19][k]);
-        }
-        free(e1sum); free(cnt);
-    }
+    /* ---- EdgeContext (model.py:135-139)   [k_edge_gate] */
+    edge_context(N, E, D, C, P + 12, edge_attr, dst, gate, rowbuf);
 
     /* ---- residual blocks (model.py:523-528)   [k_gemm mode 0 + k_aggregate_graph] */
     for (int l = 0; l < n_layers; ++l) {
@@ -312,59 +403,7 @@ int ggo_resgcn_forward(const float* const* P, int D, int n_layers,
     }
 
     /* ---- GlobalContextModule (model.py:176-188) with _graph_softmax (:90-108)   [k_jk's score + k_graph_ctx] */
-    {
-        const float* aw = P[b0 + 6];
-        const float* ab = P[b0 + 7];
-        const int Dp = padded_width(D);                                /* the kernels' width: channels >= D are zeros */
-        const int LPR = Dp <= 32 ? 8 : (Dp <= 64 ? 16 : 32);          /* lanes per row, 4 consecutive channels each */
-        float* score = (float*)malloc((size_t)N * sizeof(float));
-        for (int i = 0; i < N; ++i) {
-            float v[32];
-            const float* hr = tmp + (size_t)i * D;
-            for (int l = 0; l < LPR; ++l) {
-                float p[4];
-                for (int u = 0; u < 4; ++u) p[u] = 4 * l + u < D ? hr[4 * l + u] * aw[4 * l + u] : 0.0f;
-                v[l] = ((p[0] + p[1]) + p[2]) + p[3];
-            }
-            score[i] = butterfly(v, LPR) + ab[0];
-        }
-        /* graphs are contiguous node ranges (PyG Batch); one 256-thread block per graph */
-        const int NG = 256 / Dp;
-        float* gs = (float*)malloc((size_t)n_graphs * D * sizeof(float));
-        int beg = 0;
-        for (int q = 0; q < n_graphs; ++q) {
-            int end = beg;
-            if (batch) { while (end < N && (int)batch[end] == q) ++end; } else end = N;
-            float peak = -INFINITY;
-            for (int i = beg; i < end; ++i) if (score[i] > peak) peak = score[i];
-            float red[256];
-            for (int t = 0; t < 256; ++t) { float sacc = 0.0f; for (int i = beg + t; i < end; i += 256) sacc += ggc_expf(score[i] - peak); red[t] = sacc; }
-            for (int o = 128; o > 0; o >>= 1) for (int t = 0; t < o; ++t) red[t] += red[t + o];
-            const float tot = red[0] + 1e-12f;             /* model.py:108 (absorbed in float32 for any non-empty graph) */
-            float* g = rowbuf;                             /* weighted sum: NG strided groups per channel, then added in group order */
-            for (int k = 0; k < D; ++k) {
-                float v = 0.0f;
-                for (int grp = 0; grp < NG; ++grp) {
-                    float acc = 0.0f;
-                    for (int i = beg + grp; i < end; i += NG) acc += (ggc_expf(score[i] - peak) / tot) * tmp[(size_t)i * D + k];
-                    v += acc;
-                }
-                g[k] = v;
-            }
-            float* c = rowbuf + D;
-            linear_row(g, P[b0 + 8], P[b0 + 9], D, Dh, c);
-            for (int k = 0; k < Dh; ++k) c[k] = c[k] > 0.0f ? c[k] : 0.0f;
-            float* ex = rowbuf + 2 * D;
-            linear_row(c, P[b0 + 10], NULL, Dh, D, ex);
-            for (int k = 0; k < D; ++k) gs[(size_t)q * D + k] = sigmoid_f(ex[k] + P[b0 + 11][k]);
-            beg = end;
-        }
-        for (int i = 0; i < N; ++i) {
-            int q = batch ? (int)batch[i] : 0;
-            for (int k = 0; k < D; ++k) tmp2[(size_t)i * D + k] = tmp[(size_t)i * D + k] * gs[(size_t)q * D + k];
-        }
-        free(score); free(gs);
-    }
+    global_context(N, D, tmp, batch, n_graphs, P + b0 + 6, tmp2, rowbuf, NULL);
 
     /* ---- fuse + head (model.py:491-497,536) and softmax (:543-546)   [k_gemm mode 2] */
     for (int i = 0; i < N; ++i) {

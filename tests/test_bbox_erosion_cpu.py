@@ -16,13 +16,16 @@ from gcn_grabcut.pipeline import eroded_box
     (120, 160, (100, 60, 60, 60)),       # touches the right and bottom edges
     (120, 160, (40, 40, 29, 50)),        # narrower than the kernel: empty core
     (120, 160, (40, 40, 30, 30)),        # exactly the kernel: one pixel
-    (64, 64, (-5, -5, 40, 40)),          # box sticking out of the frame
+    (64, 64, (-5, -5, 40, 40)),          # negative corner: numpy's slice [-5:35] of 64 rows is empty, like in the reference
+    (64, 64, (-30, 10, 50, 40)),         # x = -30: columns [-30:20] -> [34:20], empty
+    (64, 64, (-50, -50, 60, 60)),        # [-50:10] -> [14:10], empty
+    (64, 64, (20, 30, 100, 100)),        # stop past the frame: cut at the edge, which is then not eroded
 ])
 @pytest.mark.parametrize("ksize", [30, 5])
 def test_eroded_box_equals_binary_erosion(H, W, bbox, ksize):
     x, y, w, h = bbox
     inner = np.zeros((H, W), bool)
-    inner[max(y, 0):max(y + h, 0), max(x, 0):max(x + w, 0)] = True
+    inner[y:y + h, x:x + w] = True          # the reference's fill (pipeline.py:368), numpy slice semantics included
     want = ndimage.binary_erosion(inner, structure=np.ones((ksize, ksize), bool), border_value=1)
     y0, y1, x0, x1 = eroded_box(H, W, bbox, ksize)
     got = np.zeros((H, W), bool)

@@ -113,3 +113,37 @@ def test_seeded_augmentation_follows_the_reference_draw_order(tmp_path):
         assert tuple(ds._bgr_to_hsv8(px)[0, 0]) == hsv and tuple(ds._hsv8_to_bgr(np.array([[hsv]], np.uint8))[0, 0]) == bgr
     back = ds._hsv8_to_bgr(ds._bgr_to_hsv8(img))
     assert np.abs(back.astype(int) - img.astype(int)).max() <= 4           # 8-bit round trip (H has 2-degree steps)
+
+
+def test_seeded_augmentation_is_the_same_on_worker_threads(tmp_path):
+    """prepare_dataset decodes on a thread pool (the reference uses worker PROCESSES, each with its own `random`): the seeded
+    copy must not depend on which thread makes it or on what the other threads draw meanwhile — and random.Random(seed) is
+    the stream random.seed(seed) gives, so the reference's parameter sequence is kept."""
+    import random
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 255, (96, 128, 3), dtype=np.uint8)
+    mask = np.zeros((96, 128), np.uint8); mask[20:80, 30:100] = 255
+    _write(tmp_path / "i.png", img[:, :, ::-1]); _write(tmp_path / "m.png", mask)
+    descs = [{"image_path": str(tmp_path / "i.png"), "mask_path": str(tmp_path / "m.png"), "max_size": 512, "name": f"i{k}",
+              "aug_seed": 1000 + k} for k in range(32)]
+    serial = [ds.materialise(d) for d in descs]
+    for _ in range(3):
+        with ThreadPoolExecutor(4) as pool:
+            threaded = list(pool.map(ds.materialise, descs))
+        for a, b in zip(serial, threaded):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert np.array_equal(a["image"], b["image"]) and np.array_equal(a["gt_mask"], b["gt_mask"])
+    # the private generator draws what the seeded global one would: augment_sample with the module-level `random` after
+    # random.seed(s) (the reference's way) gives the same copy
+    plain = ds.materialise({**descs[0], "aug_seed": None})
+    state = random.getstate()
+    try:
+        random.seed(1003)
+        via_global = ds.augment_sample(plain["image"], plain["gt_mask"], prob_flip=0.5, prob_rotate=0.4, prob_color=0.6, prob_crop=0.4)
+    finally:
+        random.setstate(state)
+    via_private = ds.augment_sample(plain["image"], plain["gt_mask"], prob_flip=0.5, prob_rotate=0.4, prob_color=0.6, prob_crop=0.4,
+                                    rng=random.Random(1003))
+    assert np.array_equal(via_global[0], via_private[0]) and np.array_equal(via_global[1], via_private[1])

@@ -87,3 +87,15 @@ def test_pipeline_with_gat(oracle, gpu_ctx):
         assert np.array_equal(out["trimap"][i].cpu().numpy(), tri)
         binary, *_ = oracle.grabcut(imgs[i], tri, 5, 0, None, i)
         assert np.array_equal(out["binary_mask"][i].cpu().numpy(), oracle.clean_mask(binary, 0.002, False))
+
+
+def test_input_self_loops_are_refused(gpu_ctx):
+    """PyG's GATv2Conv removes i -> i edges before it adds its own mean-filled loops; this build keeps every input edge, so
+    it refuses such input (the graph builder never produces one) instead of answering differently from the reference."""
+    m, _ = seeded_gat(32, 2, seed=1)
+    m = m.to("cuda").eval()
+    x, ei, ea = superpixel_like_graph(n=40, seed=3)
+    ei = np.concatenate([ei, np.array([[5], [5]], ei.dtype)], 1)
+    ea = np.concatenate([ea, ea[:1]], 0)
+    with pytest.raises(ValueError, match="self-loops"):
+        m(_data(x, ei, ea))

@@ -290,3 +290,30 @@ def test_config4_1080p_4000_superpixels(oracle):
     one = pipe.segment_batch_device(pipe._eng.to_device(imgs[1:]))                 # batch of one == its row of the batch of two
     assert torch.equal(one["segments"][0], out["segments"][1]) and torch.equal(one["trimap"][0], out["trimap"][1])
     assert torch.equal(one["binary_mask"][0], out["binary_mask"][1])
+
+
+def test_software_pipeline_gives_the_one_chunk_outputs(oracle, gpu_ctx):
+    """segment_batch_device(chunks=n): the front stages of chunk k+1 run under the GrabCut of chunk k.  Images are
+    independent and image b keeps seed + b, so every output — label maps, packed graphs, probabilities, trimaps, masks,
+    overlays — equals the one-chunk run bit for bit, for equal and for unequal chunks."""
+    import torch
+    from helpers import seeded_state_dict
+    from gcn_grabcut import GCNGrabCutPipeline, SuperpixelGraphConfig
+    from gcn_grabcut.synthetic import synthetic_batch
+    model, _ = seeded_state_dict(64, 3, seed=2)
+    pipe = GCNGrabCutPipeline(model.eval(), sp_config=SuperpixelGraphConfig(n_segments=120), device="cuda:0")
+    bgr = torch.from_numpy(synthetic_batch(22, 96, 128, config_id=5)).cuda()
+    ref = pipe.segment_batch_device(bgr)
+    assert pipe.chunk_plan(22, 3, 1.0) == [(0, 7), (7, 15), (15, 22)] and pipe.chunk_plan(5, 9, 0.8)[-1][1] == 5
+    for chunks, ratio in ((3, 1.0), (4, 0.6), (2, 0.8)):
+        pipe.chunk_ratio = ratio
+        timing = {}
+        out = pipe.segment_batch_device(bgr, chunks=chunks, timing=timing if chunks == 3 else None)
+        for k in ("segments", "trimap", "gc_mask", "binary_mask", "probs", "overlay", "rgba"):
+            assert torch.equal(out[k], ref[k]), (chunks, k)
+        g, r = out["graphs"], ref["graphs"]
+        assert torch.equal(g.x, r.x) and torch.equal(g.edge_src, r.edge_src) and torch.equal(g.edge_dst, r.edge_dst)
+        assert torch.equal(g.edge_attr, r.edge_attr) and torch.equal(g.node_ptr, r.node_ptr)
+        assert (g.node_ptr_host == r.node_ptr_host).all() and (g.edge_ptr_host == r.edge_ptr_host).all()
+        if chunks == 3:
+            assert {"graph_build", "grabcut", "postprocess", "wall"} <= set(timing) and timing["grabcut"] > 0
