@@ -1821,7 +1821,9 @@ __global__ void __launch_bounds__(256) k_gat_attn(int N, const int32_t* __restri
                                                   const int32_t* __restrict__ eid, const float* __restrict__ edge_attr,
                                                   const float* __restrict__ xl, const float* __restrict__ xr, GatW w,
                                                   float* __restrict__ out) {
-    constexpr int NC = (D + 63) / 64, C = D / HEADS;          // C in {4, 8, 16}: a head is C consecutive lanes
+    constexpr int NC = (D + 63) / 64, C = D / HEADS;          // a head is C consecutive channels: C <= 64 consecutive lanes of one
+                                                              // register, or (C = 128: D = 128, one head) all lanes of both
+    static_assert(C >= 4 && (C & (C - 1)) == 0 && (C <= 64 || (C == 128 && NC == 2)), "head width: a power of two from 4 to 128");
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     float bl[NC], att[NC], we[NC][EDGE_CH];
@@ -1862,9 +1864,10 @@ __global__ void __launch_bounds__(256) k_gat_attn(int N, const int32_t* __restri
                 m = m > 0.0f ? m : 0.2f * m;
                 float v = m * att[j];
 #pragma unroll
-                for (int o = C / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                for (int o = (C < 64 ? C : 64) / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
                 lg[j] = v;
             }
+            if (C == 128) { const float t = lg[0] + lg[NC - 1]; lg[0] = t; lg[NC - 1] = t; }     // one head across both registers: low half + high half
         };
         float mx[NC], lgs[NC];
         logit(am, xli, lgs);                                   // self loop
@@ -2005,7 +2008,7 @@ template <int D>
 static int forward_gat_t(ggc_ctx* ctx, hipStream_t st, int G, int N, int E, const float* x, const int32_t* edge_src,
                          const int32_t* edge_dst, const float* edge_attr, const int32_t* node_ptr, float* logits, float* probs) {
     ResgcnWeights& m = ctx->model3;
-    constexpr int HEADS = 8;
+    const int heads = m.Q;
     const int n = m.n_layers;
     const size_t ND = (size_t)N * D;
     int32_t* row_ptr = scratch_t<int32_t>(ctx, S_CSR_ROWPTR, (size_t)N + 1);
@@ -2053,7 +2056,10 @@ static int forward_gat_t(ggc_ctx* ctx, hipStream_t st, int G, int N, int E, cons
                devp(m, c + "bias"), devp(m, ln + "weight"), devp(m, ln + "bias")};
         {
             ProfScope prof(ctx, st, "gat_attention");
-            hipLaunchKernelGGL((k_gat_attn<D, HEADS>), dim3(wave_blocks), dim3(256), 0, st, N, row_ptr, col, eid, edge_attr, xl, xr, w, act);
+            if (heads == 8) hipLaunchKernelGGL((k_gat_attn<D, 8>), dim3(wave_blocks), dim3(256), 0, st, N, row_ptr, col, eid, edge_attr, xl, xr, w, act);
+            else if (heads == 4) hipLaunchKernelGGL((k_gat_attn<D, 4>), dim3(wave_blocks), dim3(256), 0, st, N, row_ptr, col, eid, edge_attr, xl, xr, w, act);
+            else if (heads == 2) hipLaunchKernelGGL((k_gat_attn<D, 2>), dim3(wave_blocks), dim3(256), 0, st, N, row_ptr, col, eid, edge_attr, xl, xr, w, act);
+            else hipLaunchKernelGGL((k_gat_attn<D, 1>), dim3(wave_blocks), dim3(256), 0, st, N, row_ptr, col, eid, edge_attr, xl, xr, w, act);
         }
         GGC_LAUNCH_CHECK(ctx);
         if ((rc = launch_edge_gate<D, true>(ctx, st, N, row_ptr, eid, csr_dst, edge_attr, devp(m, "#" + g + "proj.0.weightT"),
@@ -2089,10 +2095,11 @@ int ggc_gat_configure(ggc_ctx* ctx, int hidden, int n_heads, int n_layers) {
     if (!ctx) return GGC_E_INVALID_ARG;
     GGC_REQUIRE(ctx, hidden == 32 || hidden == 64 || hidden == 128, GGC_E_UNSUPPORTED,
                 "hidden_channels=%d unsupported: GATTrimapNet runs at 32, 64 or 128 (a head must span a power-of-two number of lanes)", hidden);
-    GGC_REQUIRE(ctx, n_heads == 8, GGC_E_UNSUPPORTED, "n_heads=%d unsupported: the attention kernel is built for the reference's 8 heads", n_heads);
+    GGC_REQUIRE(ctx, n_heads == 1 || n_heads == 2 || n_heads == 4 || n_heads == 8, GGC_E_UNSUPPORTED,
+                "n_heads=%d unsupported: 1, 2, 4 or 8 (the reference's default is 8)", n_heads);
     GGC_REQUIRE(ctx, n_layers >= 1 && n_layers <= 30, GGC_E_INVALID_ARG, "n_layers=%d out of range [1,30]", n_layers);
     ResgcnWeights& m = ctx->model3;
-    if (m.D != hidden || m.n_layers != n_layers) m.host.clear();
+    if (m.D != hidden || m.n_layers != n_layers) m.host.clear();     // (the head count changes no weight shape: att is [1, H, D / H] = D values)
     m.D = hidden; m.n_layers = n_layers; m.Q = n_heads; m.dev_ok = false;
     return GGC_OK;
 }

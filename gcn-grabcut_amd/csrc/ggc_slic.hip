@@ -262,6 +262,11 @@ __global__ void __launch_bounds__(256) k_slic_assign(SlicGeom g, const float* __
 //    they are taken as integer popcount / lane-local sums (a cluster that large falls back to the ordered loop);
 //  * the colour fold walks the set bits of each group's ballot in ascending x with one ds_bpermute per channel,
 //    all groups in the same wave instruction.  Same additions, same order, a fraction of the instructions.
+// Measured in round 3 and not kept (same label maps each time): (a) a MEMBER BOX per cluster, grown by k_slic_assign with
+// integer min / max (ballots per wave, a 64-slot LDS table per block, 4 global atomics per cluster and block) and scanned
+// here instead of the (4 step + 1)^2 window — this kernel 0.58 -> 0.44 ms per sweep, but the assignment 0.42 -> 0.60: the
+// scan is not what bounds the update, the ordered fold is; (b) one LANE per cluster walking its member box with plain
+// predicated adds — 0.60 ms per sweep: 64 clusters per wave-load are 32-64 cache lines.
 constexpr int UPD_LANES = 8, UPD_GROUPS = 64 / UPD_LANES, UPD_CH = 8;
 
 __global__ void __launch_bounds__(256) k_slic_update(SlicGeom g, const float* __restrict__ image,

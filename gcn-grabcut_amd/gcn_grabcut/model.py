@@ -427,7 +427,7 @@ if _TORCH:
         """
         GATv2 attention variant with edge features (reference model.py:323-414; SURVEY.md section 8(f), last rank).  Same
         `state_dict` keys as the reference module.  Inference only: the forward pass runs in libggc_hip.so
-        (`ggc_gat_forward`) on an MI355X — there is no CPU fallback.  Widths 32, 64 or 128 with the reference's 8 heads.
+        (`ggc_gat_forward`) on an MI355X — there is no CPU fallback.  Widths 32, 64 or 128 with 1, 2, 4 or 8 heads.
         """
 
         def __init__(self, in_channels: int = N_NODE_FEATS, edge_channels: int = N_EDGE_FEATS, hidden_channels: int = 128,
@@ -435,9 +435,9 @@ if _TORCH:
             super().__init__()
             if in_channels != N_NODE_FEATS or edge_channels != N_EDGE_FEATS or n_classes != 3:
                 raise ValueError("the MI355X kernels are built for 19 node features, 5 edge features and 3 classes")
-            if hidden_channels not in (32, 64, 128) or n_heads != 8:
-                raise ValueError("GATTrimapNet on MI355X: hidden_channels in {32, 64, 128} with n_heads = 8 "
-                                 "(a head must span a power-of-two number of lanes)")
+            if hidden_channels not in (32, 64, 128) or n_heads not in (1, 2, 4, 8):
+                raise ValueError("GATTrimapNet on MI355X: hidden_channels in {32, 64, 128} with n_heads in {1, 2, 4, 8} "
+                                 "(a head must span a power-of-two number of lanes; the reference's default is 128 x 8)")
             self.n_classes, self.n_heads, self.hidden_channels, self.n_layers = n_classes, n_heads, hidden_channels, n_layers
             self.in_norm = _InputNorm(in_channels)
             self.input_proj = nn.Sequential(nn.Linear(in_channels, hidden_channels), nn.LayerNorm(hidden_channels), nn.GELU())

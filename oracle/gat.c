@@ -29,7 +29,7 @@
 #define IN_CH 19
 #define EDGE_CH 5
 #define N_CLS 3
-#define HEADS 8
+#define MAX_HEADS 8
 
 int ggo_gat_n_params(int n_layers) { return 8 + 13 * n_layers + 11; }
 
@@ -67,12 +67,13 @@ static void mfma_row(const float* a, const float* W, int D, float* acc) {       
     }
 }
 
-/* attention logits of one edge for all heads: lg[h] */
+/* attention logits of one edge for all heads: lg[h].  A head's C = D / heads channels sit on C consecutive lanes (one
+ * butterfly); with ONE head at D = 128 the head spans both registers of a lane: low 64 channels + high 64 channels. */
 static void edge_logits(const float* attr, const float* xri, const float* xlj, const float* We /*[D,5]*/, const float* att, int D,
-                        float* lg) {
-    const int C = D / HEADS;
-    for (int h = 0; h < HEADS; ++h) {
-        float v[16];
+                        int heads, float* lg) {
+    const int C = D / heads;
+    for (int h = 0; h < heads; ++h) {
+        float v[128];
         for (int cc = 0; cc < C; ++cc) {
             const int c = h * C + cc;
             float ev = 0.0f;
@@ -81,13 +82,15 @@ static void edge_logits(const float* attr, const float* xri, const float* xlj, c
             m = m > 0.0f ? m : 0.2f * m;
             v[cc] = m * att[c];
         }
-        lg[h] = butterfly(v, C);                           /* the head's C consecutive lanes */
+        lg[h] = C <= 64 ? butterfly(v, C) : butterfly(v, 64) + butterfly(v + 64, 64);
     }
 }
 
-int ggo_gat_forward(const float* const* P, int D, int n_layers, int N, int E, const float* x, const int64_t* edge_index,
+int ggo_gat_forward(const float* const* P, int D, int heads, int n_layers, int N, int E, const float* x, const int64_t* edge_index,
                     const float* edge_attr, const int64_t* batch, int n_graphs, float* logits, float* probs) {
     if (!(D == 32 || D == 64 || D == 128)) return -2;
+    if (!(heads == 1 || heads == 2 || heads == 4 || heads == 8)) return -2;
+    const int HEADS = heads;
     const int C = D / HEADS, Dh = D / 2;
     const int64_t* src = edge_index;
     const int64_t* dst = edge_index + E;
@@ -139,13 +142,13 @@ int ggo_gat_forward(const float* const* P, int D, int n_layers, int N, int E, co
             for (int p = beg; p < end; ++p) for (int k = 0; k < EDGE_CH; ++k) am[k] += edge_attr[(size_t)eids[p] * EDGE_CH + k];
             const float cf = (float)(cnt > 0 ? cnt : 1);
             for (int k = 0; k < EDGE_CH; ++k) am[k] = am[k] / cf;
-            float mx[HEADS], lgs[HEADS], lg[HEADS], ssum[HEADS];
-            edge_logits(am, xri, xli, We, att, D, lgs);
+            float mx[MAX_HEADS], lgs[MAX_HEADS], lg[MAX_HEADS], ssum[MAX_HEADS];
+            edge_logits(am, xri, xli, We, att, D, heads, lgs);
             for (int hh = 0; hh < HEADS; ++hh) mx[hh] = lgs[hh];
             for (int p = beg; p < end; ++p) {
                 const int64_t j = src[eids[p]];
                 for (int k = 0; k < D; ++k) xlj[k] = xl[(size_t)j * D + k] + bl[k];
-                edge_logits(edge_attr + (size_t)eids[p] * EDGE_CH, xri, xlj, We, att, D, lg);
+                edge_logits(edge_attr + (size_t)eids[p] * EDGE_CH, xri, xlj, We, att, D, heads, lg);
                 for (int hh = 0; hh < HEADS; ++hh) mx[hh] = fmaxf(mx[hh], lg[hh]);
             }
             for (int hh = 0; hh < HEADS; ++hh) ssum[hh] = 0.0f;
@@ -153,7 +156,7 @@ int ggo_gat_forward(const float* const* P, int D, int n_layers, int N, int E, co
             for (int p = beg; p < end; ++p) {
                 const int64_t j = src[eids[p]];
                 for (int k = 0; k < D; ++k) xlj[k] = xl[(size_t)j * D + k] + bl[k];
-                edge_logits(edge_attr + (size_t)eids[p] * EDGE_CH, xri, xlj, We, att, D, lg);
+                edge_logits(edge_attr + (size_t)eids[p] * EDGE_CH, xri, xlj, We, att, D, heads, lg);
                 for (int hh = 0; hh < HEADS; ++hh) {
                     const float e = ggc_expf(lg[hh] - mx[hh]);
                     ssum[hh] += e;

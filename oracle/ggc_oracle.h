@@ -92,9 +92,9 @@ int ggo_edge_injection(const float* const* Q, int D, int N, int E, const float* 
 int ggo_gcnnet_n_params(int n_layers);
 int ggo_gcnnet_forward(const float* const* params, int D, int n_layers, int N, int E, const float* x,
                        const int64_t* edge_index, const float* edge_attr, float* logits, float* probs);
-/* GATTrimapNet (model.py:323-414), 8 heads, D in {32, 64, 128}; parameter order in gat.c */
+/* GATTrimapNet (model.py:323-414), heads in {1, 2, 4, 8}, D in {32, 64, 128}; parameter order in gat.c */
 int ggo_gat_n_params(int n_layers);
-int ggo_gat_forward(const float* const* params, int D, int n_layers, int N, int E, const float* x, const int64_t* edge_index,
+int ggo_gat_forward(const float* const* params, int D, int heads, int n_layers, int N, int E, const float* x, const int64_t* edge_index,
                     const float* edge_attr, const int64_t* batch, int n_graphs, float* logits, float* probs);
 int ggo_resgcn_forward(const float* const* params, int D, int n_layers,
                        int N, int E, const float* x, const int64_t* edge_index,

@@ -176,8 +176,8 @@ def gat_param_order(n_layers: int) -> list[str]:
     return keys
 
 
-def gat_forward(state: dict, hidden: int, n_layers: int, x, edge_index, edge_attr, batch=None):
-    """GATTrimapNet (eval, 8 heads). state: {key: np.ndarray}. Returns (logits, probs) float32 (N,3)."""
+def gat_forward(state: dict, hidden: int, n_layers: int, x, edge_index, edge_attr, batch=None, heads: int = 8):
+    """GATTrimapNet (eval; heads in {1, 2, 4, 8}). state: {key: np.ndarray}. Returns (logits, probs) float32 (N,3)."""
     L = lib()
     keys = gat_param_order(n_layers)
     assert L.ggo_gat_n_params(n_layers) == len(keys)
@@ -191,7 +191,7 @@ def gat_forward(state: dict, hidden: int, n_layers: int, x, edge_index, edge_att
     ng = 1 if b is None else int(b.max()) + 1
     logits = np.empty((n, 3), np.float32)
     probs = np.empty((n, 3), np.float32)
-    rc = L.ggo_gat_forward(ptrs, _i(hidden), _i(n_layers), _i(n), _i(e), _p(x), _p(ei), _p(ea), _p(b), _i(ng), _p(logits), _p(probs))
+    rc = L.ggo_gat_forward(ptrs, _i(hidden), _i(heads), _i(n_layers), _i(n), _i(e), _p(x), _p(ei), _p(ea), _p(b), _i(ng), _p(logits), _p(probs))
     assert rc == 0, rc
     return logits, probs
 

@@ -32,6 +32,16 @@ def test_forward_matches_oracle(oracle, gpu_ctx, hidden, layers, n):
     assert np.array_equal(m.predict_probs(d), want_p)
 
 
+@pytest.mark.parametrize("hidden,heads", [(32, 1), (32, 4), (64, 2), (64, 1), (128, 4), (128, 2), (128, 1)])
+def test_other_head_counts_match_oracle(oracle, gpu_ctx, hidden, heads):
+    m, sd = seeded_gat(hidden, 2, seed=hidden + heads, heads=heads)
+    m = m.to("cuda").eval()
+    x, ei, ea = superpixel_like_graph(n=257, seed=heads)
+    want, want_p = oracle.gat_forward(_st(sd), hidden, 2, x, ei, ea, heads=heads)
+    d = _data(x, ei, ea)
+    assert np.array_equal(m(d).cpu().numpy(), want) and np.array_equal(m.predict_probs(d), want_p)
+
+
 def test_batched_equals_single_and_oracle(oracle, gpu_ctx):
     from gcn_grabcut.data import Batch
     m, sd = seeded_gat(128, 5, seed=7)

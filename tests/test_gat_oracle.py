@@ -9,11 +9,11 @@ import torch_ref
 from helpers import superpixel_like_graph
 
 
-def seeded_gat(hidden=64, n_layers=3, seed=0):
+def seeded_gat(hidden=64, n_layers=3, seed=0, heads=8):
     """Reference-style init plus perturbed norm statistics / biases so that every term is exercised."""
     from gcn_grabcut.model import GATTrimapNet
     torch.manual_seed(seed)
-    m = GATTrimapNet(hidden_channels=hidden, n_layers=n_layers).eval()
+    m = GATTrimapNet(hidden_channels=hidden, n_layers=n_layers, n_heads=heads).eval()
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for k, v in m.state_dict().items():
@@ -45,7 +45,8 @@ def test_state_dict_layout_and_parameter_count():
     want = 38 + (19 * d + d + 2 * d) + n * (conv + 2 * d + (5 * d + d + d * d + d)) + d * d + (d + 1 + d * d // 2 + d // 2 + d * d // 2 + d) \
         + (d * d + d + 3 * d + 3)
     assert sum(p.numel() for p in m.parameters()) == want
-    for bad in (dict(hidden_channels=96), dict(n_heads=4), dict(hidden_channels=48)):
+    assert GATTrimapNet(hidden_channels=64, n_heads=2, n_layers=1).state_dict()["convs.0.att"].shape == (1, 2, 32)
+    for bad in (dict(hidden_channels=96), dict(n_heads=3), dict(n_heads=16), dict(hidden_channels=48)):
         with pytest.raises(ValueError):
             GATTrimapNet(**bad)
 
@@ -60,6 +61,18 @@ def test_oracle_matches_torch_restatement(oracle, hidden, layers, n):
     assert np.abs(got_l - want_l.numpy()).max() <= 1e-4
     assert np.abs(got_p - want_p.numpy()).max() <= 1e-5
     assert np.allclose(got_p.sum(1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("hidden,heads", [(32, 1), (32, 4), (64, 2), (64, 1), (128, 4), (128, 2), (128, 1)])
+def test_other_head_counts_match_the_torch_restatement(oracle, hidden, heads):
+    """reference model.py:323-414 takes any n_heads that divides hidden_channels; this build runs 1, 2, 4 and 8 heads
+    (a head of C = hidden / heads channels sits on C consecutive lanes; one head at 128 spans both registers of a lane)"""
+    m, sd = seeded_gat(hidden, 2, seed=hidden + heads, heads=heads)
+    x, ei, ea = superpixel_like_graph(n=90, seed=heads)
+    want_l, want_p = torch_ref.gat_forward(sd, 2, torch.as_tensor(x), torch.as_tensor(ei), torch.as_tensor(ea), heads=heads)
+    st = {k: v.numpy() for k, v in sd.items() if v.dtype.is_floating_point}
+    got_l, got_p = oracle.gat_forward(st, hidden, 2, x, ei, ea, heads=heads)
+    assert np.abs(got_l - want_l.numpy()).max() <= 1e-4 and np.abs(got_p - want_p.numpy()).max() <= 1e-5
 
 
 def test_oracle_batched_equals_single_and_isolated_nodes(oracle):
