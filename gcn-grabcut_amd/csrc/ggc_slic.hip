@@ -767,8 +767,7 @@ extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, co
         GaussW gw{};
         gw.r = (int)(4.0 * (double)sigma + 0.5);
         GGC_REQUIRE(ctx, gw.r <= MAX_RADIUS, GGC_E_UNSUPPORTED, "sigma=%g needs radius %d > %d", sigma, gw.r, MAX_RADIUS);
-        const double s2 = (double)sigma * (double)sigma;
-        for (int i = -gw.r; i <= gw.r; ++i) gw.w[i + gw.r] = std::exp(-0.5 / s2 * (double)(i * i));
+        ggc_gaussian_taps((double)sigma, gw.r, gw.w);                      // numpy's exp values at sigma = 1 (include/ggc_fmath.h)
         const double sum = np_pairwise_sum(gw.w, 2 * gw.r + 1);
         for (int i = 0; i < 2 * gw.r + 1; ++i) gw.w[i] = gw.w[i] / sum;
         GGC_REQUIRE(ctx, H <= 65535, GGC_E_SHAPE, "H=%d exceeds the launch grid", H);
@@ -808,6 +807,290 @@ extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, co
     const double seg_size = (double)P / (double)g.K;
     const int min_size = (int)(0.5 * seg_size), max_size = (int)(3.0 * seg_size);
     return enforce_connectivity(ctx, st, B, H, W, raw, min_size, max_size, segments, n_nodes);
+}
+
+// =====================================================================================================================
+// use_lab=False: the reference hands `self.rgb.astype(float)` to slic (graph_builder.py:177-179).  A float64 input keeps every
+// stage of skimage's slic in float64 (rgb2lab, the Gaussian — including its pass along the depth-1 axis — and the double
+// instance of _slic_cython), so this is the path above once more in double.  It is the reference's NON-default option:
+// the kernels are plain (no packed math, one cluster per 8-lane group as above), bit-exact against oracle/slic.c's
+// ggo_slic_rgb, which is pinned against scikit-image 0.18.3 (tests/golden/skimage_0183_rgb.npz).
+namespace ggc {
+
+__global__ void __launch_bounds__(256) k_minmax_u8(size_t n, const uint8_t* __restrict__ img, int32_t* __restrict__ mm) {
+    const uint8_t* im = img + (size_t)blockIdx.y * n;
+    int lo = 255, hi = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = im[i];
+        lo = min(lo, v); hi = max(hi, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[2 * blockIdx.y], lo); atomicMax(&mm[2 * blockIdx.y + 1], hi); }
+}
+__global__ void k_minmax_u8_init(int B, int32_t* mm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { mm[2 * i] = 255; mm[2 * i + 1] = 0; }
+}
+
+// rgb.astype(float) -> min-max rescale -> rgb2lab, all float64; first pass of the Gaussian (depth axis of length 1) folded in
+__global__ void __launch_bounds__(256) k_rgb_lab64(size_t P, const uint8_t* __restrict__ bgr, const int32_t* __restrict__ mm,
+                                                   GaussW g, int smooth, double* __restrict__ out) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const size_t base = ((size_t)blockIdx.y * P + p) * 3;
+    const double mn = (double)mm[2 * blockIdx.y], mx = (double)mm[2 * blockIdx.y + 1];
+    const double range = mx - mn;
+    double lin[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double v = (double)bgr[base + 2 - c];                              // R, G, B
+        v = v - mn; if (mx != mn) v = v / range;
+        lin[c] = v > 0.04045 ? det_pow24((v + 0.055) / 1.055) : v / 12.92;
+    }
+    const double X = (lin[0] * 0.412453 + lin[1] * 0.357580) + lin[2] * 0.180423;
+    const double Y = (lin[0] * 0.212671 + lin[1] * 0.715160) + lin[2] * 0.072169;
+    const double Z = (lin[0] * 0.019334 + lin[1] * 0.119193) + lin[2] * 0.950227;
+    const double t[3] = {X / 0.95047, Y / 1.0, Z / 1.08883};
+    double f[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f[c] = t[c] > 0.008856 ? det_cbrt(t[c]) : 7.787 * t[c] + 16.0 / 116.0;
+    double lab[3] = {116.0 * f[1] - 16.0, 500.0 * (f[0] - f[1]), 200.0 * (f[1] - f[2])};
+    if (smooth) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                                      // every tap of the length-1 reflected axis is the pixel itself
+            double tmp = lab[c] * g.w[g.r];
+            for (int jj = -g.r; jj < 0; ++jj) tmp += (lab[c] + lab[c]) * g.w[jj + g.r];
+            lab[c] = tmp;
+        }
+    }
+    out[base + 0] = lab[0]; out[base + 1] = lab[1]; out[base + 2] = lab[2];
+}
+
+template <int AXIS>
+__global__ void __launch_bounds__(256) k_gauss64(int H, int W, const double* __restrict__ in, GaussW g, double scale,
+                                                 int apply_scale, double* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;                        // x * 3 + c
+    if (col >= 3 * W) return;
+    const int y = blockIdx.y;
+    const size_t n = (size_t)H * W * 3;
+    const double* im = in + (size_t)blockIdx.z * n;
+    const int x = col / 3, c = col - 3 * x;
+    const int l = AXIS == 0 ? y : x;
+    const int len = AXIS == 0 ? H : W;
+    auto at = [&](int idx) -> double {
+        const int j = reflect_sym(idx, len);
+        return AXIS == 0 ? im[((size_t)j * W + x) * 3 + c] : im[((size_t)y * W + j) * 3 + c];
+    };
+    double tmp = at(l) * g.w[g.r];
+    for (int jj = -g.r; jj < 0; ++jj) tmp += (at(l + jj) + at(l - jj)) * g.w[jj + g.r];
+    if (apply_scale) tmp = tmp * scale;
+    out[(size_t)blockIdx.z * n + (size_t)y * W * 3 + col] = tmp;
+}
+__global__ void __launch_bounds__(256) k_scale64(size_t n, const double* __restrict__ in, double scale, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * scale;
+}
+
+__device__ __forceinline__ int4 slic_window64(double cy, double cx, const SlicGeom& g) {
+    if (cy != cy || cx != cx) return make_int4(0, 0, 0, 0);
+    double fy0 = cy - (double)(2 * g.win_y); if (!(fy0 > 0.0)) fy0 = 0.0;
+    double fy1 = cy + (double)(2 * g.win_y) + 1.0; if (!(fy1 < (double)g.H)) fy1 = (double)g.H;
+    double fx0 = cx - (double)(2 * g.win_x); if (!(fx0 > 0.0)) fx0 = 0.0;
+    double fx1 = cx + (double)(2 * g.win_x) + 1.0; if (!(fx1 < (double)g.W)) fx1 = (double)g.W;
+    return make_int4((int)fy0, (int)fy1, (int)fx0, (int)fx1);
+}
+__global__ void k_init_centers64(SlicGeom g, double* __restrict__ centers, int4* __restrict__ bounds) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= g.K) return;
+    const size_t o = (size_t)blockIdx.y * g.K + k;
+    const double cy = (double)(g.start_y + (k / g.nx) * g.step_y), cx = (double)(g.start_x + (k % g.nx) * g.step_x);
+    centers[o * 5 + 0] = cy; centers[o * 5 + 1] = cx;
+    centers[o * 5 + 2] = 0.0; centers[o * 5 + 3] = 0.0; centers[o * 5 + 4] = 0.0;
+    bounds[o] = slic_window64(cy, cx, g);
+}
+
+struct Cand64 { int k, y0, y1, x0, x1; double cy, cx, c0, c1, c2; };
+
+// pixel-centric assignment as k_slic_assign (candidates of a 32x8 tile compacted in ascending k, strict '>'), one pixel per thread
+__global__ void __launch_bounds__(256) k_slic_assign64(SlicGeom g, double sw, const double* __restrict__ image,
+                                                       const double* __restrict__ centers, const int4* __restrict__ bounds,
+                                                       int32_t* __restrict__ labels, int32_t* __restrict__ stale) {
+    __shared__ Cand64 cand[256];
+    __shared__ int wcount[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8;
+    const int px = tx0 + (tid & 31), py = ty0 + (tid >> 5);
+    const bool in = px < g.W && py < g.H;
+    const size_t P = (size_t)g.H * g.W;
+    const size_t p = (size_t)b * P + (size_t)py * g.W + px;
+    double i0 = 0.0, i1 = 0.0, i2 = 0.0;
+    if (in) { i0 = image[3 * p]; i1 = image[3 * p + 1]; i2 = image[3 * p + 2]; }
+    double best = INFINITY;
+    int lab = -1;
+    const double* cen = centers + (size_t)b * g.K * 5;
+    const int4* bnd = bounds + (size_t)b * g.K;
+    for (int base = 0; base < g.K; base += 256) {
+        const int k = base + tid;
+        bool hit = false;
+        int4 bd = make_int4(0, 0, 0, 0);
+        if (k < g.K) {
+            bd = bnd[k];
+            hit = bd.x < ty0 + 8 && bd.y > ty0 && bd.z < tx0 + 32 && bd.w > tx0 && bd.y > bd.x && bd.w > bd.z;
+        }
+        const unsigned long long bal = __ballot(hit);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wave) off += wcount[w]; total += wcount[w]; }
+        if (hit) {
+            Cand64 c;
+            c.k = k; c.y0 = bd.x; c.y1 = bd.y; c.x0 = bd.z; c.x1 = bd.w;
+            c.cy = cen[k * 5 + 0]; c.cx = cen[k * 5 + 1]; c.c0 = cen[k * 5 + 2]; c.c1 = cen[k * 5 + 3]; c.c2 = cen[k * 5 + 4];
+            cand[off + pre] = c;
+        }
+        __syncthreads();
+        for (int i = 0; i < total; ++i) {
+            const Cand64& c = cand[i];
+            if (!((unsigned)(px - c.x0) < (unsigned)(c.x1 - c.x0) && (unsigned)(py - c.y0) < (unsigned)(c.y1 - c.y0))) continue;
+            const double ty = c.cy - (double)py, tx = c.cx - (double)px;
+            double dd = (ty * ty + tx * tx) * sw;
+            double t = i0 - c.c0, dc = t * t;
+            t = i1 - c.c1; dc += t * t;
+            t = i2 - c.c2; dc += t * t;
+            dd += dc;
+            if (best > dd) { best = dd; lab = c.k; }
+        }
+        __syncthreads();
+    }
+    if (in) { if (lab >= 0) labels[p] = lab; else atomicOr(&stale[b], 1); }
+}
+
+// centre update as k_slic_update (8-lane group per cluster, ordered colour fold), sums in double
+__global__ void __launch_bounds__(256) k_slic_update64(SlicGeom g, const double* __restrict__ image, const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ stale, double* __restrict__ centers,
+                                                       int4* __restrict__ bounds) {
+    const int lane = threadIdx.x & 63, sub = lane / UPD_LANES, sl = lane % UPD_LANES;
+    const int k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * UPD_GROUPS + sub;
+    const bool live = k < g.K;
+    const int b = blockIdx.y;
+    const size_t o = (size_t)b * g.K + (live ? k : 0);
+    int4 bd = live ? bounds[o] : make_int4(0, 0, 0, 0);
+    if (live && stale[b]) bd = make_int4(0, g.H, 0, g.W);
+    const size_t P = (size_t)g.H * g.W;
+    const int32_t* lb = labels + (size_t)b * P;
+    const double* im = image + (size_t)b * P * 3;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    long long cnt = 0, isy = 0, isx = 0;                    // integer coordinate sums: exact in double far beyond any image
+    const int rows = bd.y - bd.x, cols = bd.w - bd.z;
+    int rows_max = rows, cols_max = cols;
+#pragma unroll
+    for (int off = UPD_LANES; off < 64; off <<= 1) {
+        rows_max = max(rows_max, __shfl_xor(rows_max, off, 64));
+        cols_max = max(cols_max, __shfl_xor(cols_max, off, 64));
+    }
+    for (int ry = 0; ry < rows_max; ++ry) {
+        const int y = bd.x + ry;
+        for (int c0 = 0; c0 < cols_max; c0 += UPD_LANES) {
+            const int x = bd.z + c0 + sl;
+            const bool hit = live && ry < rows && x < bd.w && lb[(size_t)y * g.W + x] == k;
+            const unsigned long long bal = __ballot(hit);
+            if (!bal) continue;
+            unsigned int m = (unsigned int)(bal >> (sub * UPD_LANES)) & ((1u << UPD_LANES) - 1u);
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+            if (hit) { const double* px = im + ((size_t)y * g.W + x) * 3; v0 = px[0]; v1 = px[1]; v2 = px[2]; isx += x; }
+            const int n = __popc(m);
+            cnt += n; isy += (long long)n * y;
+            while (__any(m != 0u)) {
+                const int src = sub * UPD_LANES + (m ? __ffs((int)m) - 1 : 0);
+                const double t0 = __shfl(v0, src, 64), t1 = __shfl(v1, src, 64), t2 = __shfl(v2, src, 64);
+                if (m) { s0 += t0; s1 += t1; s2 += t2; }
+                m &= m - 1u;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < UPD_LANES; off <<= 1) isx += __shfl_xor(isx, off, 64);
+    if (!live || sl != 0) return;
+    const double n = (double)cnt;
+    const double cy = (double)isy / n, cx = (double)isx / n;
+    centers[o * 5 + 0] = cy; centers[o * 5 + 1] = cx;
+    centers[o * 5 + 2] = s0 / n; centers[o * 5 + 3] = s1 / n; centers[o * 5 + 4] = s2 / n;
+    bounds[o] = slic_window64(cy, cx, g);
+}
+
+} // namespace ggc
+
+extern "C" int ggc_slic_rgb(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, const uint8_t* bgr, int n_segments,
+                            double compactness, double sigma, int32_t* segments, int32_t* n_nodes) {
+    if (!ctx) return GGC_E_INVALID_ARG;
+    GGC_REQUIRE(ctx, B >= 1 && H >= 1 && W >= 1 && B <= 65535 && H <= 65535, GGC_E_SHAPE, "bad shape B=%d H=%d W=%d", B, H, W);
+    GGC_REQUIRE(ctx, bgr && segments && n_nodes, GGC_E_INVALID_ARG, "null pointer");
+    GGC_REQUIRE(ctx, n_segments >= 1 && compactness > 0.0 && sigma >= 0.0, GGC_E_INVALID_ARG,
+                "bad SLIC parameters n_segments=%d compactness=%g sigma=%g", n_segments, compactness, sigma);
+    GGC_REQUIRE(ctx, (size_t)H * W < (1u << 30), GGC_E_SHAPE, "image too large");
+    GGC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t P = (size_t)H * W;
+    const Grid seed = regular_grid(H, W, n_segments);
+    GGC_REQUIRE(ctx, seed.K >= 1, GGC_E_SHAPE, "no SLIC seeds for %dx%d with n_segments=%d", H, W, n_segments);
+    const Grid win = regular_grid(H, W, seed.K);
+    SlicGeom g{};
+    g.H = H; g.W = W; g.K = seed.K;
+    g.ny = seed.ny; g.nx = seed.nx; g.start_y = seed.start_y; g.start_x = seed.start_x;
+    g.step_y = seed.step_y; g.step_x = seed.step_x;
+    g.win_y = win.step_y; g.win_x = win.step_x;
+    const double step = (double)std::max(std::max(seed.step_y, seed.step_x), 1);
+    const double sw = 1.0 / (step * step);
+
+    double* img_a = scratch_t<double>(ctx, S_SLIC_IMG, (size_t)B * P * 3);
+    double* img_b = scratch_t<double>(ctx, S_SLIC_TMP, (size_t)B * P * 3);
+    int32_t* mm = scratch_t<int32_t>(ctx, S_SLIC_MINMAX, (size_t)B * 2);
+    double* centers = scratch_t<double>(ctx, S_SLIC_CENTERS, (size_t)B * g.K * 5);
+    int4* bounds = scratch_t<int4>(ctx, S_SLIC_AUX, (size_t)B * g.K);
+    int32_t* raw = scratch_t<int32_t>(ctx, S_SLIC_LABELS, (size_t)B * P);
+    int32_t* stale = scratch_t<int32_t>(ctx, S_SLIC_AUX2, (size_t)B * 10);
+    if (!img_a || !img_b || !mm || !centers || !bounds || !raw || !stale) return GGC_E_OOM;
+
+    GaussW gw{};
+    const int smooth = sigma > 0.0 ? 1 : 0;
+    if (smooth) {
+        gw.r = (int)(4.0 * sigma + 0.5);
+        GGC_REQUIRE(ctx, gw.r <= MAX_RADIUS, GGC_E_UNSUPPORTED, "sigma=%g needs radius %d > %d", sigma, gw.r, MAX_RADIUS);
+        ggc_gaussian_taps(sigma, gw.r, gw.w);
+        const double sum = np_pairwise_sum(gw.w, 2 * gw.r + 1);
+        for (int i = 0; i < 2 * gw.r + 1; ++i) gw.w[i] = gw.w[i] / sum;
+    }
+    hipLaunchKernelGGL(k_minmax_u8_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, mm);
+    hipLaunchKernelGGL(k_minmax_u8, dim3(std::min(cdiv(P * 3, 256 * 8), 48), B), dim3(256), 0, st, P * 3, bgr, mm);
+    hipLaunchKernelGGL(k_rgb_lab64, dim3(cdiv(P, 256), B), dim3(256), 0, st, P, bgr, mm, gw, smooth, img_a);
+    GGC_LAUNCH_CHECK(ctx);
+    const double ratio = 1.0 / compactness;
+    const double* km_img;
+    if (smooth) {
+        const dim3 grid(cdiv((size_t)W * 3, 256), H, B);
+        hipLaunchKernelGGL((k_gauss64<0>), grid, dim3(256), 0, st, H, W, img_a, gw, 1.0, 0, img_b);
+        hipLaunchKernelGGL((k_gauss64<1>), grid, dim3(256), 0, st, H, W, img_b, gw, ratio, 1, img_a);
+        km_img = img_a;
+    } else {
+        hipLaunchKernelGGL(k_scale64, dim3(cdiv((size_t)B * P * 3, 256)), dim3(256), 0, st, (size_t)B * P * 3, img_a, ratio, img_b);
+        km_img = img_b;
+    }
+    GGC_LAUNCH_CHECK(ctx);
+    GGC_HIP(ctx, hipMemsetAsync(raw, 0, sizeof(int32_t) * (size_t)B * P, st));
+    GGC_HIP(ctx, hipMemsetAsync(stale, 0, sizeof(int32_t) * (size_t)B * 10, st));
+    hipLaunchKernelGGL(k_init_centers64, dim3(cdiv(g.K, 256), B), dim3(256), 0, st, g, centers, bounds);
+    for (int it = 0; it < 10; ++it) {
+        hipLaunchKernelGGL(k_slic_assign64, dim3(cdiv(W, 32), cdiv(H, 8), B), dim3(256), 0, st, g, sw, km_img, centers, bounds, raw,
+                           stale + (size_t)it * B);
+        hipLaunchKernelGGL(k_slic_update64, dim3(cdiv(g.K, 4 * UPD_GROUPS), B), dim3(256), 0, st, g, km_img, raw, stale + (size_t)it * B,
+                           centers, bounds);
+        GGC_LAUNCH_CHECK(ctx);
+    }
+    const double seg_size = (double)P / (double)g.K;
+    return enforce_connectivity(ctx, st, B, H, W, raw, (int)(0.5 * seg_size), (int)(3.0 * seg_size), segments, n_nodes);
 }
 
 // Step 7 alone (skimage's _enforce_label_connectivity_cython) — exposed so the parity

@@ -134,6 +134,15 @@ class Engine:
                       float(sigma), int(bool(rescale_input)), seg.data_ptr(), n.data_ptr())
         return seg, n
 
+    def slic_rgb(self, bgr: torch.Tensor, n_segments: int, compactness: float = 10.0, sigma: float = 1.0):
+        """SuperpixelGraphConfig(use_lab=False): SLIC on rgb.astype(float), skimage's float64 path (reference graph_builder.py:177-179)."""
+        b, h, w, _ = bgr.shape
+        seg = self.empty(b, h, w, dtype=torch.int32)
+        n = self.empty(b, dtype=torch.int32)
+        self.ctx.call("ggc_slic_rgb", self._stream(), b, h, w, bgr.data_ptr(), int(n_segments), float(compactness), float(sigma),
+                      seg.data_ptr(), n.data_ptr())
+        return seg, n
+
     # ------------------------------------------------------------------ G2-G8
     def build_graphs(self, seg, n_nodes, lab, hsv, grad, connectivity: int = 4, n_nonlocal: int = 4) -> DeviceGraphs:
         b, h, w = seg.shape

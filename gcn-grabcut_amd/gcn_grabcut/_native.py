@@ -35,6 +35,7 @@ SIGNATURES = {
     "ggc_debug_read_scratch": [_vp, C.c_char_p, _vp, C.c_size_t],
     "ggc_preprocess": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ggc_slic": [_vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _i, _vp, _vp],
+    "ggc_slic_rgb": [_vp, _vp, _i, _i, _i, _vp, _i, _d, _d, _vp, _vp],
     "ggc_slic_enforce_connectivity": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "ggc_graph_prior_sigmas": [_vp, _d, _d],
     "ggc_graph_count": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],

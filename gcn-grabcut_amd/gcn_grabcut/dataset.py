@@ -315,7 +315,8 @@ def _build_batch(eng, images: np.ndarray, gt_masks: np.ndarray, cfg: SuperpixelG
     b, h, w, _ = images.shape
     bgr = eng.to_device(images)
     lab, hsv, _gray, grad = eng.preprocess(bgr)
-    seg, n_nodes = eng.slic(lab, cfg.n_segments, cfg.compactness, cfg.sigma)
+    seg, n_nodes = eng.slic(lab, cfg.n_segments, cfg.compactness, cfg.sigma) if cfg.use_lab else \
+        eng.slic_rgb(bgr, cfg.n_segments, cfg.compactness, cfg.sigma)              # reference graph_builder.py:177-179
     g = eng.build_graphs(seg, n_nodes, lab, hsv, grad, cfg.connectivity, cfg.n_nonlocal)
     n_total = int(g.node_ptr_host[-1])
     counts = eng.empty(max(n_total, 1), dtype=torch.int32)
@@ -343,8 +344,6 @@ def prepare_sample(sample: dict, sp_config: Optional[SuperpixelGraphConfig] = No
     """One sample -> (Data, labels, segments) — reference dataset.py:213-260."""
     from ._engine import get_engine
     cfg = sp_config or SuperpixelGraphConfig()
-    if not cfg.use_lab:
-        raise NotImplementedError("use_lab=False (SLIC on raw RGB) is not on the MI355X hot path")
     rec = _build_batch(get_engine(device), sample["image"][None], sample["gt_mask"][None], cfg, fg_threshold, bg_threshold)
     return rec[0]
 
@@ -361,8 +360,6 @@ def prepare_dataset(samples: list[dict], sp_config: Optional[SuperpixelGraphConf
     """
     from ._engine import get_engine
     cfg = sp_config or SuperpixelGraphConfig()
-    if not cfg.use_lab:
-        raise NotImplementedError("use_lab=False (SLIC on raw RGB) is not on the MI355X hot path")
     eng = get_engine(device)
     cache_dir = Path(cache_dir) if cache_dir else None
     t0 = time.perf_counter()

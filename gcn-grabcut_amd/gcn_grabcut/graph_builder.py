@@ -125,9 +125,10 @@ class GraphBuilder:
 
     def build_device(self):
         cfg = self.config
-        if not cfg.use_lab:
-            raise NotImplementedError("use_lab=False (SLIC on raw RGB) is not on the MI355X hot path")
-        seg, n = self._eng.slic(self._lab, cfg.n_segments, cfg.compactness, cfg.sigma)
+        if cfg.use_lab:
+            seg, n = self._eng.slic(self._lab, cfg.n_segments, cfg.compactness, cfg.sigma)
+        else:                                      # reference graph_builder.py:177-179: slic(self.rgb.astype(float), ...)
+            seg, n = self._eng.slic_rgb(self._bgr_d, cfg.n_segments, cfg.compactness, cfg.sigma)
         return self._eng.build_graphs(seg, n, self._lab, self._hsv, self._grad, cfg.connectivity, cfg.n_nonlocal)
 
     def build(self) -> SuperpixelGraph:

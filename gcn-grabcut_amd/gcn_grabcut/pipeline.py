@@ -216,7 +216,8 @@ class GCNGrabCutPipeline:
         cfg = self.sp_config
         t = tick() if tick else 0.0
         lab, hsv, gray, grad = eng.preprocess(bgr)
-        seg, n_nodes = eng.slic(lab, cfg.n_segments, cfg.compactness, cfg.sigma)
+        seg, n_nodes = eng.slic(lab, cfg.n_segments, cfg.compactness, cfg.sigma) if cfg.use_lab else \
+            eng.slic_rgb(bgr, cfg.n_segments, cfg.compactness, cfg.sigma)          # reference graph_builder.py:177-179
         graphs = eng.build_graphs(seg, n_nodes, lab, hsv, grad, cfg.connectivity, cfg.n_nonlocal)
         if timing is not None:
             timing["graph_build"] = tick() - t
@@ -261,8 +262,6 @@ class GCNGrabCutPipeline:
         cs = self.gc_config.color_space.lower()
         if cs not in ("rgb", "hsv", "lab"):
             raise ValueError(f"unknown color_space '{cs}': rgb | hsv | lab")
-        if not cfg.use_lab:
-            raise NotImplementedError("use_lab=False is not on the MI355X hot path")
         b = bgr.size(0)
         want = self.grabcut_lanes if grabcut_lanes is None else int(grabcut_lanes)   # (an argument, so that concurrent callers do not mutate the pipeline)
         n_chunks = self.chunks if chunks is None else int(chunks)

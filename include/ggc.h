@@ -121,6 +121,14 @@ int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
              const float* image, int n_segments, float compactness, float sigma,
              int rescale_input, int32_t* segments, int32_t* n_nodes);
 
+/* The same for SuperpixelGraphConfig(use_lab=False) (graph_builder.py:177-179): skimage.segmentation.slic on
+ * `rgb.astype(float)`, i.e. the float64 instance of every stage (min-max rescale, rgb2lab, Gaussian, k-means).
+ *   bgr      [dev] u8 [B,H,W,3]    (the image itself: the reference converts BGR -> RGB -> float64)
+ */
+int ggc_slic_rgb(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W,
+                 const uint8_t* bgr, int n_segments, double compactness, double sigma,
+                 int32_t* segments, int32_t* n_nodes);
+
 /* Step 7 of ggc_slic alone — skimage's _enforce_label_connectivity_cython
  * (SURVEY Appendix A.1): raw_labels, segments [dev] i32 [B,H,W]; n_nodes [dev] i32 [B].
  * SYNCHRONISES the stream once per carve round (components of >= max_size pixels). */

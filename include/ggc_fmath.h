@@ -77,4 +77,17 @@ GGC_FM_FN float ggc_geluf(float x) {
     return x * (x >= 0.0f ? 1.0f - hq : hq);
 }
 
+/* Unnormalised taps exp(-0.5 i^2 / sigma^2), i = -r..r, of scipy.ndimage's Gaussian (scipy/ndimage/filters.py, _gaussian_kernel1d).
+ * scipy evaluates them with numpy's vectorised exp, which differs from libm's in the last bit for three of the five values at
+ * sigma = 1 — invisible after the float32 rounding of the Lab path, visible in the float64 path (use_lab=False).  For sigma = 1,
+ * the setting of the reference's config, the values are the ones numpy 1.26 returns; other sigmas use libm (last-bit unpinned). */
+static inline void ggc_gaussian_taps(double sigma, int r, double* w /*[2r+1]*/) {
+    static const double s1[5] = {0x1.0000000000000p+0, 0x1.368b2fc6f960ap-1, 0x1.152aaa3bf81cbp-3, 0x1.6c0504695c418p-7, 0x1.5fc21041027acp-12};
+    const double s2 = sigma * sigma;
+    for (int i = -r; i <= r; ++i) {
+        const int a = i < 0 ? -i : i;
+        w[i + r] = (sigma == 1.0 && a < 5) ? s1[a] : exp(-0.5 / s2 * (double)(i * i));
+    }
+}
+
 #endif /* GGC_FMATH_H */

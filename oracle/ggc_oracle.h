@@ -49,6 +49,11 @@ void ggo_preprocess(int H, int W, const uint8_t* bgr,
 /* ---- G1: skimage slic as called at graph_builder.py:180-187 ---- */
 /* individual steps, exposed for pinning against skimage/scipy */
 void ggo_slic_rescale_lab(int H, int W, const float* image, int rescale_input, float* out);
+/* the float64 instance of the same steps: SuperpixelGraphConfig(use_lab=False) = slic(rgb.astype(float)) (graph_builder.py:177-179) */
+void ggo_slic_rescale_lab64(int H, int W, const double* image, int rescale_input, double* out);
+void ggo_gaussian_f64(int H, int W, int C, const double* in, double sigma, double* out);
+void ggo_slic_kmeans64(int H, int W, const double* image, int K, double* centers, double step, int max_iter, int32_t* labels);
+int  ggo_slic_rgb(int H, int W, const uint8_t* bgr, int n_segments, double compactness, double sigma, int32_t* segments);
 void ggo_gaussian_f32(int H, int W, int C, const float* in, double sigma, float* out);
 int  ggo_gaussian_weights(double sigma, double* w /*[2r+1]*/, int cap); /* returns radius */
 int  ggo_slic_grid(int H, int W, int n_segments, int* step_y, int* step_x,

@@ -290,6 +290,47 @@ def slic(image, n_segments, compactness=10.0, sigma=1.0, rescale_input=True):
     return seg, n
 
 
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def slic_rescale_lab64(image, rescale_input=True):
+    """float64 instance (use_lab=False): min-max rescale + rgb2lab in double"""
+    image = f64(image)
+    h, w = image.shape[:2]
+    out = np.empty_like(image)
+    lib().ggo_slic_rescale_lab64(_i(h), _i(w), _p(image), _i(int(rescale_input)), _p(out))
+    return out
+
+
+def gaussian64(image, sigma=1.0):
+    image = f64(image)
+    h, w, c = image.shape
+    out = np.empty_like(image)
+    lib().ggo_gaussian_f64(_i(h), _i(w), _i(c), _p(image), _d(sigma), _p(out))
+    return out
+
+
+def slic_kmeans64(image, seeds_yx, step, max_iter=10):
+    image = f64(image)
+    h, w = image.shape[:2]
+    k = seeds_yx.shape[0]
+    centers = np.zeros((k, 5), np.float64)
+    centers[:, :2] = seeds_yx
+    labels = np.empty((h, w), np.int32)
+    lib().ggo_slic_kmeans64(_i(h), _i(w), _p(image), _i(k), _p(centers), _d(step), _i(max_iter), _p(labels))
+    return labels, centers
+
+
+def slic_rgb(bgr, n_segments, compactness=10.0, sigma=1.0):
+    """SuperpixelGraphConfig(use_lab=False): slic(rgb.astype(float), ...) — reference graph_builder.py:177-188"""
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w = bgr.shape[:2]
+    seg = np.empty((h, w), np.int32)
+    n = lib().ggo_slic_rgb(_i(h), _i(w), _p(bgr), _i(n_segments), _d(compactness), _d(sigma), _p(seg))
+    return seg, n
+
+
 # ---------------------------------------------------------------- G2-G8
 
 def find_boundaries_inner(seg):
@@ -457,13 +498,13 @@ def eval_counts(pred, gt, trimap=None, width=3):
 
 def segment(bgr, state, hidden, n_layers, n_segments=300, compactness=10.0, sigma=1.0, connectivity=4,
             n_nonlocal=4, threshold_fg=0.55, threshold_bg=0.55, n_iter=5, refine_iters=0, min_area_ratio=0.002,
-            keep_largest=False, edge_aware=True, filter_radius=8, seed=0, timing=None):
+            keep_largest=False, edge_aware=True, filter_radius=8, seed=0, timing=None, use_lab=True):
     """CPU restatement of GCNGrabCutPipeline.segment (reference pipeline.py:265-352), stage by stage.
     `state` is the ResGCNNet state_dict as numpy arrays.  Returns a dict of host arrays."""
     import time
     t0 = time.perf_counter()
     lab, hsv, gray, grad = preprocess(bgr)
-    seg, n = slic(lab, n_segments, compactness, sigma, True)
+    seg, n = slic(lab, n_segments, compactness, sigma, True) if use_lab else slic_rgb(bgr, n_segments, compactness, sigma)
     g = graph_build(seg, lab, hsv, grad, connectivity, n_nonlocal)
     t1 = time.perf_counter()
     x = np.concatenate([g["node_features"], g["prior"]], 1)

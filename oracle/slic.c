@@ -19,6 +19,7 @@
  * comment says f64.
  */
 #include "ggc_oracle.h"
+#include "../include/ggc_fmath.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -78,8 +79,7 @@ static int reflect_sym(int i, int n) { /* scipy mode='reflect': (d c b a | a b c
 int ggo_gaussian_weights(double sigma, double* w /*[2r+1]*/, int cap) {
     const int r = (int)(4.0 * sigma + 0.5);
     if (2 * r + 1 > cap) return -1;
-    const double s2 = sigma * sigma;
-    for (int i = -r; i <= r; ++i) w[i + r] = exp(-0.5 / s2 * (double)(i * i));
+    ggc_gaussian_taps(sigma, r, w);                     /* numpy's exp values at sigma = 1 (include/ggc_fmath.h) */
     const double sum = np_pairwise_sum(w, 2 * r + 1);
     for (int i = 0; i < 2 * r + 1; ++i) w[i] = w[i] / sum;
     return r;
@@ -244,6 +244,152 @@ int ggo_slic_connectivity(int H, int W, const int32_t* labels, int min_size, int
     int mx = 0;
     for (size_t p = 0; p < P; ++p) if (out[p] > mx) mx = out[p];
     return mx + 1; /* n_nodes = segments.max() + 1 (graph_builder.py:158) */
+}
+
+/* =====================================================================================================================
+ * The float64 path: SuperpixelGraphConfig(use_lab=False) hands `self.rgb.astype(float)` to slic (graph_builder.py:177-179).
+ * A float64 input keeps every stage of skimage's slic in float64 — img_as_float leaves it alone, rgb2lab, gaussian_filter and
+ * the double instance of _slic_cython's fused type (slic_superpixels.py:231-317 of 0.18.3) — so the steps above are restated
+ * once more in double.  Pinned bit-exact (Gaussian, k-means, connectivity) / to 1e-12 (rgb2lab: numpy's pow and cbrt) against
+ * scikit-image 0.18.3 + scipy 1.7.1 by tests/test_slic_oracle.py with tests/golden/skimage_0183_rgb.npz. */
+void ggo_slic_rescale_lab64(int H, int W, const double* image, int rescale_input, double* out) {
+    const size_t n = (size_t)H * W * 3;
+    double mn = image[0], mx = image[0];
+    for (size_t i = 1; i < n; ++i) { if (image[i] < mn) mn = image[i]; if (image[i] > mx) mx = image[i]; }
+    const double range = mx - mn;
+    const double m[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+    for (size_t p = 0; p < (size_t)H * W; ++p) {
+        double lin[3];
+        for (int c = 0; c < 3; ++c) {
+            double v = image[3 * p + c];
+            if (rescale_input) { v = v - mn; if (mx != mn) v = v / range; }
+            lin[c] = v > 0.04045 ? ggo_pow24((v + 0.055) / 1.055) : v / 12.92;
+        }
+        double xyz[3];
+        for (int r = 0; r < 3; ++r) xyz[r] = (lin[0] * m[3 * r] + lin[1] * m[3 * r + 1]) + lin[2] * m[3 * r + 2];
+        const double t[3] = {xyz[0] / 0.95047, xyz[1] / 1.0, xyz[2] / 1.08883};
+        double f[3];
+        for (int c = 0; c < 3; ++c) f[c] = t[c] > 0.008856 ? ggo_cbrt(t[c]) : 7.787 * t[c] + 16.0 / 116.0;
+        out[3 * p + 0] = 116.0 * f[1] - 16.0;
+        out[3 * p + 1] = 500.0 * (f[0] - f[1]);
+        out[3 * p + 2] = 200.0 * (f[1] - f[2]);
+    }
+}
+
+static void gauss_axis64(int H, int W, int C, const double* in, double* out, const double* w, int r, int axis) {
+    const int len = axis == 0 ? H : W;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int c = 0; c < C; ++c) {
+                const int l = axis == 0 ? y : x;
+#define AT(idx) (axis == 0 ? in[((size_t)reflect_sym((idx), len) * W + x) * C + c] : in[((size_t)y * W + reflect_sym((idx), len)) * C + c])
+                double tmp = AT(l) * w[r];
+                for (int jj = -r; jj < 0; ++jj) tmp += (AT(l + jj) + AT(l - jj)) * w[jj + r];
+#undef AT
+                out[((size_t)y * W + x) * C + c] = tmp;
+            }
+}
+
+void ggo_gaussian_f64(int H, int W, int C, const double* in, double sigma, double* out) {
+    double w[129];
+    const int r = ggo_gaussian_weights(sigma, w, 129);
+    double* tmp = (double*)malloc((size_t)H * W * C * sizeof(double));
+    /* slic filters the (1, H, W, C) volume along its depth axis first: every tap of a length-1 reflected axis is the pixel
+     * itself, v w_r + sum (v + v) w_k — not exactly v in float64 (the float32 path rounds the difference away) */
+    for (size_t i = 0; i < (size_t)H * W * C; ++i) {
+        double t = in[i] * w[r];
+        for (int jj = -r; jj < 0; ++jj) t += (in[i] + in[i]) * w[jj + r];
+        out[i] = t;
+    }
+    gauss_axis64(H, W, C, out, tmp, w, r, 0);
+    gauss_axis64(H, W, C, tmp, out, w, r, 1);
+    free(tmp);
+}
+
+/* _slic_cython, double instance: ggo_slic_kmeans with every float a double */
+void ggo_slic_kmeans64(int H, int W, const double* image, int K, double* centers, double step, int max_iter, int32_t* labels) {
+    int wy, wx, d0, d1, d2, d3;
+    ggo_slic_grid(H, W, K, &wy, &wx, &d0, &d1, &d2, &d3);
+    const double sw = 1.0 / (step * step);
+    const size_t P = (size_t)H * W;
+    double* dist = (double*)malloc(P * sizeof(double));
+    int64_t* cnt = (int64_t*)malloc((size_t)K * sizeof(int64_t));
+    for (size_t p = 0; p < P; ++p) labels[p] = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        int change = 0;
+        for (size_t p = 0; p < P; ++p) dist[p] = INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const double cy = centers[5 * k + 0], cx = centers[5 * k + 1];
+            if (cy != cy || cx != cx) continue;
+            double fy0 = cy - (double)(2 * wy); if (!(fy0 > 0.0)) fy0 = 0.0;
+            double fy1 = cy + (double)(2 * wy) + 1.0; if (!(fy1 < (double)H)) fy1 = (double)H;
+            double fx0 = cx - (double)(2 * wx); if (!(fx0 > 0.0)) fx0 = 0.0;
+            double fx1 = cx + (double)(2 * wx) + 1.0; if (!(fx1 < (double)W)) fx1 = (double)W;
+            const int y0 = (int)fy0, y1 = (int)fy1, x0 = (int)fx0, x1 = (int)fx1;
+            const double c0 = centers[5 * k + 2], c1 = centers[5 * k + 3], c2 = centers[5 * k + 4];
+            for (int y = y0; y < y1; ++y) {
+                const double ty = cy - (double)y;
+                const double dy = ty * ty;
+                for (int x = x0; x < x1; ++x) {
+                    const double tx = cx - (double)x;
+                    double d = (dy + tx * tx) * sw;
+                    const double* px = image + ((size_t)y * W + x) * 3;
+                    double dc = 0.0, t;
+                    t = px[0] - c0; dc += t * t;
+                    t = px[1] - c1; dc += t * t;
+                    t = px[2] - c2; dc += t * t;
+                    d += dc;
+                    const size_t p = (size_t)y * W + x;
+                    if (dist[p] > d) { labels[p] = k; dist[p] = d; change = 1; }
+                }
+            }
+        }
+        if (!change) break;
+        memset(cnt, 0, (size_t)K * sizeof(int64_t));
+        for (int k = 0; k < 5 * K; ++k) centers[k] = 0.0;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const size_t p = (size_t)y * W + x;
+                const int k = labels[p];
+                cnt[k] += 1;
+                centers[5 * k + 0] += (double)y;
+                centers[5 * k + 1] += (double)x;
+                centers[5 * k + 2] += image[3 * p + 0];
+                centers[5 * k + 3] += image[3 * p + 1];
+                centers[5 * k + 4] += image[3 * p + 2];
+            }
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < 5; ++c) centers[5 * k + c] = centers[5 * k + c] / (double)cnt[k];
+    }
+    free(dist); free(cnt);
+}
+
+/* the whole call for use_lab=False: bgr uint8 -> rgb.astype(float) -> slic */
+int ggo_slic_rgb(int H, int W, const uint8_t* bgr, int n_segments, double compactness, double sigma, int32_t* segments) {
+    const size_t P = (size_t)H * W;
+    double* a = (double*)malloc(P * 3 * sizeof(double));
+    double* b = (double*)malloc(P * 3 * sizeof(double));
+    for (size_t p = 0; p < P; ++p) { a[3 * p] = (double)bgr[3 * p + 2]; a[3 * p + 1] = (double)bgr[3 * p + 1]; a[3 * p + 2] = (double)bgr[3 * p]; }
+    ggo_slic_rescale_lab64(H, W, a, 1, b);
+    int sy, sx, y0, x0, ny, nx;
+    const int K = ggo_slic_grid(H, W, n_segments, &sy, &sx, &y0, &x0, &ny, &nx);
+    if (sigma > 0.0) ggo_gaussian_f64(H, W, 3, b, sigma, a);
+    else memcpy(a, b, P * 3 * sizeof(double));
+    const double ratio = 1.0 / compactness;
+    for (size_t i = 0; i < P * 3; ++i) a[i] = a[i] * ratio;
+    double* centers = (double*)calloc((size_t)K * 5, sizeof(double));
+    for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) {
+            centers[5 * (j * nx + i) + 0] = (double)(y0 + j * sy);
+            centers[5 * (j * nx + i) + 1] = (double)(x0 + i * sx);
+        }
+    const double step = (double)(sy > sx ? sy : sx);
+    int32_t* raw = (int32_t*)malloc(P * sizeof(int32_t));
+    ggo_slic_kmeans64(H, W, a, K, centers, step, 10, raw);
+    const double seg_size = (double)P / (double)K;
+    const int n = ggo_slic_connectivity(H, W, raw, (int)(0.5 * seg_size), (int)(3.0 * seg_size), segments);
+    free(a); free(b); free(centers); free(raw);
+    return n;
 }
 
 /* ---- the whole call */

@@ -317,3 +317,27 @@ def test_software_pipeline_gives_the_one_chunk_outputs(oracle, gpu_ctx):
         assert (g.node_ptr_host == r.node_ptr_host).all() and (g.edge_ptr_host == r.edge_ptr_host).all()
         if chunks == 3:
             assert {"graph_build", "grabcut", "postprocess", "wall"} <= set(timing) and timing["grabcut"] > 0
+
+
+def test_use_lab_false_runs_the_float64_slic_end_to_end(oracle, gpu_ctx):
+    """SuperpixelGraphConfig(use_lab=False) (reference graph_builder.py:177-179): GraphBuilder, the pipeline and the graph-cache
+    writer take skimage's float64 SLIC on the RGB image; everything downstream is unchanged.  Label map, trimap and mask equal
+    the oracle's."""
+    import torch
+    from helpers import seeded_state_dict
+    from gcn_grabcut import GCNGrabCutPipeline, GraphBuilder, SuperpixelGraphConfig
+    from gcn_grabcut.synthetic import synthetic_batch
+    model, sd = seeded_state_dict(64, 3, seed=4)
+    st = {k: v.numpy() for k, v in sd.items() if v.dtype.is_floating_point}
+    cfg = SuperpixelGraphConfig(n_segments=150, use_lab=False)
+    pipe = GCNGrabCutPipeline(model.eval(), sp_config=cfg, device="cuda:0")
+    imgs = synthetic_batch(2, 120, 160, config_id=6)
+    res = pipe.segment_batch(list(imgs))
+    for i, r in enumerate(res):
+        want = oracle.segment(imgs[i], st, 64, 3, n_segments=150, seed=i, use_lab=False)
+        assert np.array_equal(r.segments, want["segments"]) and np.array_equal(r.trimap, want["trimap"])
+        assert np.array_equal(r.binary_mask, want["binary_mask"])
+    lab_path = GCNGrabCutPipeline(model, sp_config=SuperpixelGraphConfig(n_segments=150), device="cuda:0").segment_batch(list(imgs))
+    assert not np.array_equal(lab_path[0].segments, res[0].segments)       # it IS another segmentation than the Lab path's
+    g = GraphBuilder(imgs[0], cfg).build()
+    assert np.array_equal(g.segments, res[0].segments)

@@ -160,3 +160,42 @@ def test_connectivity_matches_on_real_kmeans_output(oracle, gpu_ctx):
         raw = GOLD[f"c{i}_raw"]
         got, n = _connectivity(gpu_ctx, raw[None], int(GOLD[f"c{i}_min_size"]), int(GOLD[f"c{i}_max_size"]))
         assert np.array_equal(got[0], GOLD[f"c{i}_connected"])
+
+
+# ---------------------------------------------------------------- use_lab=False: skimage's float64 path
+GOLD_RGB = np.load(Path(__file__).parent / "golden" / "skimage_0183_rgb.npz")
+
+
+def _slic_rgb(gpu_ctx, bgr, n_segments, compactness=10.0, sigma=1.0):
+    from gcn_grabcut import _native
+    d = torch.as_tensor(np.ascontiguousarray(bgr)).cuda().contiguous()
+    b, h, w, _ = d.shape
+    seg = torch.empty(b, h, w, dtype=torch.int32, device="cuda")
+    n = torch.empty(b, dtype=torch.int32, device="cuda")
+    gpu_ctx.call("ggc_slic_rgb", _native.current_stream(0), b, h, w, d.data_ptr(), n_segments, float(compactness), float(sigma),
+                 seg.data_ptr(), n.data_ptr())
+    return seg.cpu().numpy(), n.cpu().numpy()
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_slic_rgb_golden_inputs_bit_exact_vs_oracle_and_close_to_skimage(oracle, gpu_ctx, i):
+    """SuperpixelGraphConfig(use_lab=False) = slic(rgb.astype(float)) (reference graph_builder.py:177-179): label map identical to
+    the oracle's float64 restatement, which is pinned against scikit-image 0.18.3's double kernels (test_slic_oracle.py)."""
+    bgr = GOLD_RGB[f"r{i}_bgr"]
+    n_seg = int(GOLD_RGB[f"r{i}_n_segments"])
+    seg, n = _slic_rgb(gpu_ctx, bgr[None], n_seg)
+    want, wn = oracle.slic_rgb(bgr, n_seg)
+    assert np.array_equal(seg[0], want) and n[0] == wn
+    assert (seg[0] == GOLD_RGB[f"r{i}_connected"]).mean() > 0.97       # the whole skimage call: only pow / cbrt ulps differ
+
+
+@pytest.mark.parametrize("h,w,b,n_seg,sigma,comp", [(300, 400, 3, 600, 1.0, 10.0), (97, 131, 2, 80, 0.0, 10.0), (120, 160, 2, 150, 1.5, 20.0),
+                                                    (33, 47, 1, 2000, 1.0, 10.0)])
+def test_slic_rgb_batches_bit_exact_vs_oracle(oracle, gpu_ctx, h, w, b, n_seg, sigma, comp):
+    from gcn_grabcut.synthetic import synthetic_batch
+    bgr = synthetic_batch(b, h, w, config_id=4)
+    seg, n = _slic_rgb(gpu_ctx, bgr, n_seg, comp, sigma)
+    for k in range(b):
+        want, wn = oracle.slic_rgb(bgr[k], n_seg, comp, sigma)
+        assert np.array_equal(seg[k], want), (k, int((seg[k] != want).sum()))
+        assert n[k] == wn

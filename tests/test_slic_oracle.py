@@ -88,3 +88,52 @@ def test_whole_slic_agrees_with_skimage_wrapper(oracle, i):
     agree = (seg == c["connected"]).mean()
     assert agree > 0.97, agree
     assert np.array_equal(np.unique(seg), np.arange(n))
+
+
+# ---------------------------------------------------------------- use_lab=False: the float64 path
+# SuperpixelGraphConfig(use_lab=False) hands rgb.astype(float) to slic (reference graph_builder.py:177-179); a float64 input
+# keeps rgb2lab, the Gaussian and _slic_cython's fused-type kernel in float64.  Golden: tests/golden/make_golden_skimage_rgb.py.
+GOLD_RGB = np.load(Path(__file__).parent / "golden" / "skimage_0183_rgb.npz")
+N_RGB = 4
+
+
+def case_rgb(i):
+    pre = f"r{i}_"
+    return {k[len(pre):]: GOLD_RGB[k] for k in GOLD_RGB.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("i", range(N_RGB))
+def test_f64_second_lab_close_to_skimage(oracle, i):
+    c = case_rgb(i)
+    rgb = c["bgr"][:, :, ::-1].astype(np.float64)
+    got = oracle.slic_rescale_lab64(rgb, rescale_input=True)
+    assert np.abs(got - c["second_lab"]).max() <= 1e-12          # numpy's pow / cbrt vs the fixed sequences: a few ulp of 100
+    assert np.array_equal(got, oracle.slic_rescale_lab64(c["rescaled"], rescale_input=False))
+
+
+@pytest.mark.parametrize("i", range(N_RGB))
+def test_f64_gaussian_bit_exact_vs_scipy(oracle, i):
+    c = case_rgb(i)
+    assert np.array_equal(oracle.gaussian64(c["second_lab"], 1.0), c["smoothed"])
+
+
+@pytest.mark.parametrize("i", range(N_RGB))
+def test_f64_kmeans_bit_exact_vs_slic_cython(oracle, i):
+    c = case_rgb(i)
+    h, w = c["raw"].shape
+    g = oracle.slic_grid(h, w, int(c["n_segments"]))
+    ys = g["start_y"] + g["step_y"] * np.arange(g["ny"])
+    xs = g["start_x"] + g["step_x"] * np.arange(g["nx"])
+    seeds = np.stack(np.meshgrid(ys, xs, indexing="ij"), -1).reshape(-1, 2).astype(np.float64)
+    labels, centers = oracle.slic_kmeans64(c["scaled"], seeds, float(c["step"]))
+    assert np.array_equal(labels, c["raw"])
+    assert np.array_equal(centers, c["centers_final"][:, 1:], equal_nan=True)
+
+
+@pytest.mark.parametrize("i", range(N_RGB))
+def test_f64_whole_slic_agrees_with_skimage_wrapper(oracle, i):
+    """end to end only the last ulps of pow / cbrt differ from numpy's: the label maps agree except for a handful of pixels"""
+    c = case_rgb(i)
+    seg, n = oracle.slic_rgb(c["bgr"], int(c["n_segments"]), 10.0, 1.0)
+    assert (seg == c["connected"]).mean() > 0.97
+    assert np.array_equal(np.unique(seg), np.arange(n))
