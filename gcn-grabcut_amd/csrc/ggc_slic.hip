@@ -813,8 +813,8 @@ extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, co
 // use_lab=False: the reference hands `self.rgb.astype(float)` to slic (graph_builder.py:177-179).  A float64 input keeps every
 // stage of skimage's slic in float64 (rgb2lab, the Gaussian — including its pass along the depth-1 axis — and the double
 // instance of _slic_cython), so this is the path above once more in double.  It is the reference's NON-default option:
-// the kernels are plain (no packed math, one cluster per 8-lane group as above), bit-exact against oracle/slic.c's
-// ggo_slic_rgb, which is pinned against scikit-image 0.18.3 (tests/golden/skimage_0183_rgb.npz).
+// the kernels are plain (no packed math, one cluster per 8-lane group as above); the tests hold them bit-exact to the CPU
+// restatement of the same path, which is pinned against scikit-image 0.18.3 (tests/golden/skimage_0183_rgb.npz).
 namespace ggc {
 
 __global__ void __launch_bounds__(256) k_minmax_u8(size_t n, const uint8_t* __restrict__ img, int32_t* __restrict__ mm) {
