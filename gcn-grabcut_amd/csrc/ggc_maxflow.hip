@@ -581,6 +581,8 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             int phase = 0;
             if (kn.mf_async) {
                 for (; phase < kn.mf_relax_dense; ++phase) relax(phase);
+                // (pool size: 512 waves per 64 open images; a lane alone runs the same with 128 or 2048 — the launch is a latency
+                // chain, not throughput — and four lanes with larger pools lose to each other's waiting waves: 56.6 -> 58.9 -> 62.8 ms)
                 const int grid = (int)std::min<size_t>(ASYNC_GRID * scale, std::max<size_t>(16, cdiv((size_t)n_cur * per_image, 16)));
                 if ((rcode = maxflow_relax_async(ctx, st, d, tl, rmask, dirty, rc, dist, rl_cnt + phase % 3, rl_list[phase & 1], rl_flag[phase & 1], ring, aq,
                                                  (int)n_rt, grid, err_flag)))
