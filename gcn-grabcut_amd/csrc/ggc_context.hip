@@ -116,7 +116,7 @@ int ggc_profile_enable(ggc_ctx* ctx, int on) {
     (void)hipDeviceSynchronize();
     for (auto& r : ctx->prof) { ctx->prof_pool.push_back(r.a); ctx->prof_pool.push_back(r.b); }
     ctx->prof.clear();
-    ctx->prof_on = on != 0;
+    ctx->prof_on = on == 2 ? 2 : (on != 0 ? 1 : 0);
     if (on) {
         // An event pair around nothing does not report zero: the two markers are separate queue packets.  Calibrate
         // that offset (median of 15 empty pairs on the null stream) so that ggc_profile_query can report kernel time.

@@ -17,7 +17,7 @@ constexpr int WAVE = 64;
 
 // Scratch slots: one growing device buffer per slot, owned by the context.
 enum Slot : int {
-    S_CSR_ROWPTR = 0, S_CSR_COL, S_CSR_EID, S_CSR_CURSOR, S_DIS, S_BATCH, S_AGG_PACK,
+    S_CSR_ROWPTR = 0, S_CSR_COL, S_CSR_EID, S_CSR_CURSOR, S_CSR_SCAN, S_DIS, S_BATCH, S_AGG_PACK,
     S_STATES, S_GATE, S_XW, S_AGG, S_SCORE, S_GVEC, S_HJK,
     S_PRE_A, S_PRE_B, S_PRE_C, S_PRE_D,
     S_SLIC_IMG, S_SLIC_TMP, S_SLIC_CENTERS, S_SLIC_DIST, S_SLIC_LABELS, S_SLIC_AUX,
@@ -69,7 +69,7 @@ struct ProfRec { const char* name; hipEvent_t a, b; };
 struct ggc_ctx {
     int device = 0;
     std::string err;
-    bool prof_on = false;
+    int prof_on = 0;                       // 0 off | 1 every scope | 2 the graded kernel's scope only
     double prof_overhead_ms = 0.0;         // duration an EMPTY event pair reports (calibrated at ggc_profile_enable)
     std::vector<ggc::ProfRec> prof;        // recorded scopes since ggc_profile_enable
     std::vector<hipEvent_t> prof_pool;     // recycled events
@@ -148,7 +148,7 @@ struct DeviceOnce {
 struct ProfScope {
     ggc_ctx* ctx; hipStream_t st; hipEvent_t b = nullptr;
     ProfScope(ggc_ctx* c, hipStream_t s, const char* name) : ctx(c), st(s) {
-        if (!c->prof_on) return;
+        if (!c->prof_on || (c->prof_on == 2 && std::strcmp(name, "gcn_aggregate") != 0)) return;
         hipEvent_t ev[2];
         for (int i = 0; i < 2; ++i) {
             if (!c->prof_pool.empty()) { ev[i] = c->prof_pool.back(); c->prof_pool.pop_back(); }

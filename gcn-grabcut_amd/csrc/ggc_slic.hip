@@ -553,26 +553,35 @@ __global__ void __launch_bounds__(256) k_cn_kept(CnDims d, const int32_t* __rest
     rank[i] = (parent[i] == (int)(i % d.P) && csize[i] >= d.min_size) ? 1 : 0;
 }
 
-// per-image exclusive scan (block per image); n_nodes = max(total, 1)
+// per-image exclusive scan (block per image); n_nodes = max(total, 1).  The block walks the image in tiles of 4096
+// elements — four consecutive ones per thread, so a wave reads 1 KB at a stretch — scanning each tile through wave shuffles
+// and carrying the running total (a thread-per-chunk scan read 118 strided words per thread: 558 us per batch of 256).
 __global__ void __launch_bounds__(1024) k_cn_scan(CnDims d, int32_t* __restrict__ rank, int32_t* __restrict__ n_nodes) {
-    __shared__ int32_t part[1024];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t s_carry;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int32_t* a = rank + (size_t)b * d.P;
-    const int chunk = (d.P + 1023) / 1024;
-    const int beg = min(tid * chunk, d.P), end = min(beg + chunk, d.P);
-    int32_t s = 0;
-    for (int i = beg; i < end; ++i) s += a[i];
-    part[tid] = s;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int32_t v = tid >= off ? part[tid - off] : 0;
+    for (int base = 0; base < d.P; base += 4096) {
+        const int i0 = base + tid * 4;
+        int32_t c[4], s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[j] = i0 + j < d.P ? a[i0 + j] : 0; s += c[j]; }
+        int32_t incl = s;
+        for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        part[tid] += v;
+        int32_t run = s_carry + (incl - s), total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { if (w < wave) run += wsum[w]; total += wsum[w]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { if (i0 + j < d.P) a[i0 + j] = run; run += c[j]; }
+        __syncthreads();
+        if (tid == 0) s_carry += total;
         __syncthreads();
     }
-    int32_t run = tid ? part[tid - 1] : 0;
-    for (int i = beg; i < end; ++i) { const int32_t c = a[i]; a[i] = run; run += c; }
-    if (tid == 1023) n_nodes[b] = part[1023] > 0 ? part[1023] : 1;
+    if (tid == 0) n_nodes[b] = s_carry > 0 ? s_carry : 1;
 }
 
 // small components: replay the BFS, remember the last neighbour of an earlier component

@@ -149,7 +149,8 @@ class Context:
     def call(self, name: str, *args) -> None:
         self.check(getattr(self.lib, name)(self.handle, *args))
 
-    def profile_enable(self, on: bool = True) -> None:
+    def profile_enable(self, on=True) -> None:
+        """True / 1: every instrumented scope; 2: only the graded GCNConv aggregation; False / 0: off."""
         self.call("ggc_profile_enable", int(on))
 
     def profile_query(self, kernel: str) -> tuple[int, float]:

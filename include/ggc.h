@@ -87,7 +87,10 @@ const char* ggc_last_error(const ggc_ctx* ctx); /* ctx may be NULL: last create 
  * ("gcn_aggregate", "gcn_gemm", "slic_assign", "maxflow", ...) and waits for them.
  * An event pair around nothing does not read zero (two queue packets), so enable
  * calibrates that offset with empty pairs and query subtracts it per scope; the
- * name "#event_pair_overhead" returns the offset itself (launches = 1). */
+ * name "#event_pair_overhead" returns the offset itself (launches = 1).
+ * on = 1: every instrumented scope; on = 2: only "gcn_aggregate", the kernel the
+ * roofline grades (an event pair costs its stream ~10 us of idle time per scope, and a
+ * step has several hundred scopes); on = 0: off. */
 int ggc_profile_enable(ggc_ctx* ctx, int on);
 int ggc_profile_query(ggc_ctx* ctx, const char* kernel, int* launches, double* total_ms);
 
