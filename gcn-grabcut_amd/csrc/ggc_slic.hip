@@ -178,6 +178,9 @@ constexpr int TILE_W = 32, TILE_H = 16;     // two pixels per thread: (x, y) and
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// (Round 3 tried pruning: the winner is the lexicographic minimum of (distance, k), so candidates can be scored in any order —
+// near ones first, far ones only if their spatial term alone does not exceed every pixel's best.  Same label maps, same
+// 0.43 ms per sweep: at compactness 10 the colour term dominates the distance, the spatial bound prunes almost nothing.)
 // Pixel-centric assignment.  A block owns a 32 x 16 tile; the clusters whose search window touches the tile are
 // compacted (ballot + prefix, ascending k, so the strict '>' keeps skimage's lowest-k tie rule) into LDS once, and
 // every thread scores its TWO pixels against each candidate on the packed-f32 pipe (v_pk_*: same IEEE operations in
