@@ -23,7 +23,8 @@ const Knobs& knobs() {
         k.mf_dense_launches = num("GGC_MF_DENSE_LAUNCHES", 12, 1);
         k.mf_dense_launches0 = num("GGC_MF_DENSE_LAUNCHES0", 8, 1);
         k.mf_dense_sweeps = num("GGC_MF_DENSE_SWEEPS", 8, 1);
-        k.mf_relax_dense = num("GGC_MF_RELAX_DENSE", 2, 1);
+        k.mf_relax_dense = num("GGC_MF_RELAX_DENSE", 3, 1);
+        k.mf_partial_rounds = num("GGC_MF_PARTIAL_ROUNDS", 3, 0);
         k.agg_direct = num("GGC_AGG_DIRECT", 0, 0);
         k.slic_seq_connectivity = num("GGC_SLIC_SEQ_CONNECTIVITY", 0, 0);
         return k;

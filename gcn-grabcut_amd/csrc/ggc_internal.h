@@ -97,7 +97,8 @@ struct Knobs {
     int mf_async_sweeps;        // GGC_MF_ASYNC_SWEEPS (12): sweeps per asynchronous push visit
     int mf_dense_launches0, mf_dense_launches;   // GGC_MF_DENSE_LAUNCHES0 (8) / GGC_MF_DENSE_LAUNCHES (12): push launches of the first / a later dense round
     int mf_dense_sweeps;        // GGC_MF_DENSE_SWEEPS (8): sweeps per dense push visit
-    int mf_relax_dense;         // GGC_MF_RELAX_DENSE (2): work-list launches of a relabel before the asynchronous one takes over
+    int mf_relax_dense;         // GGC_MF_RELAX_DENSE (3): work-list launches of a relabel before the asynchronous one takes over
+    int mf_partial_rounds;      // GGC_MF_PARTIAL_ROUNDS (3): first rounds of a solve whose relabel stops after the work-list launches
     int agg_direct;             // GGC_AGG_DIRECT (0): 1 = GCNConv gather straight from L2 (k_aggregate) instead of the graph-resident kernel
     int slic_seq_connectivity;  // GGC_SLIC_SEQ_CONNECTIVITY (0): 1 = literal one-thread-per-image raster replay of skimage's connectivity pass
 };

@@ -34,7 +34,8 @@
  *   GGC_MF_ASYNC_SWEEPS=n         sweeps per asynchronous push visit (12)
  *   GGC_MF_DENSE_LAUNCHES0=n / GGC_MF_DENSE_LAUNCHES=n   push launches of the first / a later dense round (8 / 12)
  *   GGC_MF_DENSE_SWEEPS=n         sweeps per dense push visit (8)
- *   GGC_MF_RELAX_DENSE=n          work-list launches of a global relabel before the asynchronous launch takes over (2)
+ *   GGC_MF_RELAX_DENSE=n          work-list launches of a global relabel before the asynchronous launch takes over (3)
+ *   GGC_MF_PARTIAL_ROUNDS=n       first rounds of a solve whose relabel stops after those launches (3; 0 = every relabel exact)
  *   GGC_AGG_DIRECT=1              GCNConv gather straight from L2 instead of the graph-resident kernel
  *   GGC_SLIC_SEQ_CONNECTIVITY=1   literal one-thread-per-image replay of skimage's connectivity pass (A/B reference)
  * The Python binding adds GGC_HIP_LIBRARY=<path> (load another build of the library, tools/build_variant.sh).

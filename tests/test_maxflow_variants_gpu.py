@@ -47,6 +47,8 @@ print("variant ok")
 VARIANTS = {
     "async_default": {},
     "host_work_lists": {"GGC_MF_ASYNC": "0"},
+    "exact_relabel_every_round": {"GGC_MF_PARTIAL_ROUNDS": "0", "GGC_MF_RELAX_DENSE": "2"},
+    "partial_relabels_for_long": {"GGC_MF_PARTIAL_ROUNDS": "9", "GGC_MF_RELAX_DENSE": "1"},
     "cold_start_every_iteration": {"GGC_MF_WARM": "0"},
     "async_all_push_rounds": {"GGC_MF_ASYNC_PUSH_ACTIVE": "100000000", "GGC_MF_RELAX_DENSE": "1"},
     "async_tiles_32x16": {"GGC_MF_ASYNC_TILE": "16", "GGC_MF_ASYNC_SWEEPS": "16"},
