@@ -137,6 +137,34 @@ __global__ void __launch_bounds__(256) k_gauss(int H, int W, const float* __rest
     out[(size_t)blockIdx.z * n + (size_t)y * W * 3 + col] = v;
 }
 
+// The vertical pass with the radius known at compile time: a thread owns one (column, channel) and walks GV_ROWS rows down,
+// keeping the 2R+1 taps of the current row in registers and loading ONE new value per row.  Same taps in the same order per
+// output as k_gauss<0, R> (centre first, then pairs from the outermost inwards); that kernel's blocks each re-read their
+// 2R+1 input rows from memory — 3.3 GB per batch-256 launch for a 0.37 GB image (PMC), 0.43 ms.
+constexpr int GV_ROWS = 20;
+template <int R>
+__global__ void __launch_bounds__(256) k_gauss_v(int H, int W, const float* __restrict__ in, GaussW g, float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;                        // x * 3 + c
+    if (col >= 3 * W) return;
+    const size_t n = (size_t)H * W * 3;
+    const float* im = in + (size_t)blockIdx.z * n + col;
+    float* o = out + (size_t)blockIdx.z * n + col;
+    const int y0 = blockIdx.y * GV_ROWS;
+    double v[2 * R + 1];                                                   // v[j] = input row y - R + j
+#pragma unroll
+    for (int j = 0; j < 2 * R; ++j) v[j + 1] = (double)im[(size_t)reflect_sym(y0 - R + j, H) * W * 3];
+#pragma unroll 4
+    for (int y = y0; y < min(y0 + GV_ROWS, H); ++y) {
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) v[j] = v[j + 1];
+        v[2 * R] = (double)im[(size_t)reflect_sym(y + R, H) * W * 3];
+        double tmp = v[R] * g.w[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) tmp += (v[k] + v[2 * R - k]) * g.w[k];
+        o[(size_t)y * W * 3] = (float)tmp;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_scale(size_t n, const float* __restrict__ in, float scale,
                                                float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -785,7 +813,7 @@ extern "C" int ggc_slic(ggc_ctx* ctx, ggc_stream stream, int B, int H, int W, co
         GGC_REQUIRE(ctx, H <= 65535, GGC_E_SHAPE, "H=%d exceeds the launch grid", H);
         const dim3 grid(cdiv((size_t)W * 3, 256), H, B);
         if (gw.r == 4) {                                                   // sigma = 1, the pipeline's setting
-            hipLaunchKernelGGL((k_gauss<0, 4>), grid, dim3(256), 0, st, H, W, img_a, gw, 1.0f, 0, img_b);
+            hipLaunchKernelGGL((k_gauss_v<4>), dim3(cdiv((size_t)W * 3, 256), cdiv(H, GV_ROWS), B), dim3(256), 0, st, H, W, img_a, gw, img_b);
             hipLaunchKernelGGL((k_gauss<1, 4>), grid, dim3(256), 0, st, H, W, img_b, gw, ratio, 1, img_a);
         } else {
             hipLaunchKernelGGL((k_gauss<0, 0>), grid, dim3(256), 0, st, H, W, img_a, gw, 1.0f, 0, img_b);
