@@ -86,12 +86,19 @@ __device__ __forceinline__ void flush_tiles(OutList& L, int32_t* __restrict__ li
 // tile (1 next to the sink, infinity elsewhere) and puts the tile on the first work list only if it holds a pixel WITHOUT a
 // sink link — a tile whose pixels all touch the sink (59 % of the bench's pixels are definite background) is final at
 // label 1 and never needs a visit.  (Folding this pass into the first relabel launch was measured in round 3: the heavy kernel then visits every tile, 99 us against 18 + 70.)
+// It is the first kernel of a round, so it also leaves the round's bookkeeping clean (each used to be a zero-fill launch of
+// its own): BOTH membership flags of every relabel tile it looks at (tiles of closed images are never listed again), the
+// image's active-pixel count, and the words the active scan and k_done_update accumulate into (scan[0]: open images,
+// scan[4..6]: push-list counters, scan[7]: active total).  The relabel counters themselves are zeroed by k_done_update / k_open_init.
 __global__ void __launch_bounds__(256) k_mf_rinit(GcDims d, MfTiles tl, const int32_t* __restrict__ open_list,
                                                   const int32_t* __restrict__ snk, int32_t* __restrict__ dist,
-                                                  int32_t* __restrict__ list, int32_t* __restrict__ flag, int32_t* __restrict__ count) {
+                                                  int32_t* __restrict__ list, int32_t* __restrict__ flag, int32_t* __restrict__ flag2,
+                                                  int32_t* __restrict__ count, int32_t* __restrict__ active, int32_t* __restrict__ scan) {
     constexpr int T = MF_RT;
     __shared__ OutList outl;
     if (threadIdx.x == 0) outl.n = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) active[open_list[blockIdx.y]] = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8 && (threadIdx.x == 0 || threadIdx.x >= 4)) scan[threadIdx.x] = 0;   // not [1..3]: the relabel counters this launch appends to
     __syncthreads();
     const int tiles_per_image = tl.rt_x * tl.rt_y;
     const int tr = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -112,11 +119,15 @@ __global__ void __launch_bounds__(256) k_mf_rinit(GcDims d, MfTiles tl, const in
                 open_px |= sv[r] <= 0;
             }
         }
-        if (__any(open_px) && lane == 0) {
+        const bool listed = __any(open_px);
+        if (lane == 0) {
             const int tile = b * tiles_per_image + tr;
-            flag[tile] = 1;                                                // (flags were cleared before the launch; one writer per tile)
-            const int i = atomicAdd(&outl.n, 1);
-            if (i < OUT_CAP) outl.buf[i] = tile; else list[atomicAdd(count, 1)] = tile;
+            flag[tile] = listed ? 1 : 0;                                   // one writer per tile
+            flag2[tile] = 0;
+            if (listed) {
+                const int i = atomicAdd(&outl.n, 1);
+                if (i < OUT_CAP) outl.buf[i] = tile; else list[atomicAdd(count, 1)] = tile;
+            }
         }
     }
     flush_tiles(outl, list, count);
@@ -440,7 +451,7 @@ __global__ void __launch_bounds__(PT_N / PPT) k_mf_pr_list(GcDims d, MfTiles tl,
 // 920 k flag reads and LDS appends in the first round of a 64-image solve: 203 us, against ~25 us for the 61 MB it reads.)
 __global__ void __launch_bounds__(256) k_mf_active(GcDims d, MfTiles tl, const int32_t* __restrict__ open_list,
                                                    const int32_t* __restrict__ ex, const int32_t* __restrict__ dist,
-                                                   int32_t* __restrict__ active, int32_t* __restrict__ flag,
+                                                   int32_t* __restrict__ active, int32_t* __restrict__ flag, int32_t* __restrict__ flag2,
                                                    int32_t* __restrict__ list, int32_t* __restrict__ count) {
     __shared__ OutList outl;
     __shared__ int s_n;
@@ -468,12 +479,15 @@ __global__ void __launch_bounds__(256) k_mf_active(GcDims d, MfTiles tl, const i
             n += (x < d.W && y < d.H && ev[j] > 0 && dv[j] < DINF) ? 1 : 0;
         }
         for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-        if (n > 0 && lane == 0) {
+        if (lane == 0) {
             const int tile = b * tiles_per_image + tr;
-            flag[tile] = 1;                                                // (flags were cleared before the launch; one writer per tile)
-            const int i = atomicAdd(&outl.n, 1);
-            if (i < OUT_CAP) outl.buf[i] = tile; else list[atomicAdd(count, 1)] = tile;
-            n_block += n;
+            flag[tile] = n > 0 ? 1 : 0;                                    // both membership flags of every push tile of an open image: one writer
+            flag2[tile] = 0;                                               // per tile, no zero-fill launch before the scan
+            if (n > 0) {
+                const int i = atomicAdd(&outl.n, 1);
+                if (i < OUT_CAP) outl.buf[i] = tile; else list[atomicAdd(count, 1)] = tile;
+                n_block += n;
+            }
         }
     }
     if (lane == 0 && n_block) atomicAdd(&s_n, n_block);
@@ -484,14 +498,17 @@ __global__ void __launch_bounds__(256) k_mf_active(GcDims d, MfTiles tl, const i
 
 // closes images without active pixels and compacts the still-open ones into the next launch list
 __global__ void k_done_update(int n_cur, const int32_t* __restrict__ list_cur, const int32_t* __restrict__ active,
-                              int32_t* __restrict__ list_nxt, int32_t* __restrict__ n_open, int keep_all) {
+                              int32_t* __restrict__ list_nxt, int32_t* __restrict__ n_open, int keep_all, int32_t* __restrict__ rl_cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3) rl_cnt[i] = 0;                              // this round's relabel is over: its work-list counters start the next one at zero
     if (i >= n_cur) return;
     const int b = list_cur[i];
     if (active[b] != 0 || keep_all) { list_nxt[atomicAdd(n_open, 1)] = b; atomicAdd(n_open + 7, active[b]); }   // [7]: active pixels in total
 }
-__global__ void k_open_init(int B, const int32_t* __restrict__ state, int32_t* __restrict__ list, int32_t* __restrict__ n_open) {
+__global__ void k_open_init(int B, const int32_t* __restrict__ state, int32_t* __restrict__ list, int32_t* __restrict__ n_open,
+                            int32_t* __restrict__ rl_cnt) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < 3) rl_cnt[b] = 0;
     if (b < B && !state[b]) list[atomicAdd(n_open, 1)] = b;
 }
 
@@ -545,7 +562,7 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
     if (masks_exact) GGC_HIP(ctx, hipMemsetAsync(dirty, 0, sizeof(int32_t) * n_pt, st));
     if (prof_dev) GGC_HIP(ctx, hipMemsetAsync(prof_dev, 0, 128 * 8 * sizeof(long long), st));
     GGC_HIP(ctx, hipMemsetAsync(n_open, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_open_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, list_cur, n_open);
+    hipLaunchKernelGGL(k_open_init, dim3(cdiv(B, 256)), dim3(256), 0, st, B, state, list_cur, n_open, rl_cnt);
     GGC_LAUNCH_CHECK(ctx);
     std::vector<int32_t> host;
     int rcode = read_i32(ctx, st, n_open, 1, host);
@@ -574,8 +591,8 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
         int relax_launches = 0;
         {
             ProfScope prof(ctx, st, "maxflow_relabel");
-            mf_zero3(st, rl_flag[0], n_rt * 2, rl_cnt, 3, nullptr, 0);
-            hipLaunchKernelGGL(k_mf_rinit, dim3(cdiv(per_image, 4), n_cur), dim3(256), 0, st, d, tl, list_cur, snk, dist, rl_list[0], rl_flag[0], rl_cnt);
+            hipLaunchKernelGGL(k_mf_rinit, dim3(cdiv(per_image, 4), n_cur), dim3(256), 0, st, d, tl, list_cur, snk, dist, rl_list[0], rl_flag[0],
+                               rl_flag[1], rl_cnt, active, n_open);
             auto relax = [&](int phase) {
                 int32_t *li = rl_list[phase & 1], *lo = rl_list[(phase + 1) & 1], *fi = rl_flag[phase & 1], *fo = rl_flag[(phase + 1) & 1];
                 if (prof_dev) hipLaunchKernelGGL(k_mf_relax_wave<true>, dim3(rl_grid), dim3(256), 0, st, d, tl, phase, prof_dev, rmask, dirty, rc, dist, rl_cnt, li, lo, fi, fo);
@@ -609,10 +626,10 @@ int maxflow(ggc_ctx* ctx, hipStream_t st, const GcDims& d, const int32_t* state,
             }
         }
         // ---- who still has work?  (active pixel = excess that can still reach the sink)
-        mf_zero3(st, active, (size_t)B + 8, pt_flag[0], n_pt * 2, nullptr, 0);                // active, n_open, all counters, total | push flags
+        // (active[], the open-image count, the push-list counters and the active total were zeroed by this round's k_mf_rinit)
         hipLaunchKernelGGL(k_mf_active, dim3(std::min(cdiv(tl.pt_x * tl.pt_y, 4), 128), n_cur), dim3(256), 0, st, d, tl, list_cur, ex, dist,
-                           active, pt_flag[0], pt_list[0], pr_cnt);
-        hipLaunchKernelGGL(k_done_update, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, n_cur, list_cur, active, list_nxt, n_open, partial ? 1 : 0);
+                           active, pt_flag[0], pt_flag[1], pt_list[0], pr_cnt);
+        hipLaunchKernelGGL(k_done_update, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, n_cur, list_cur, active, list_nxt, n_open, partial ? 1 : 0, rl_cnt);
         GGC_LAUNCH_CHECK(ctx);
         if ((rcode = read_i32(ctx, st, n_open, 8, host))) return rcode;
         const int n_next = host[0], total_active = host[7];
