@@ -59,7 +59,7 @@ class Engine:
             self._lanes.append((Engine(self.index, private_context=True), torch.cuda.Stream(self.device)))
         return self._lanes[:n]
 
-    def grabcut_lanes(self, image, mask, n_iter=5, mode=0, seed=0, n_lanes=4, bgd=None, fgd=None):
+    def grabcut_lanes(self, image, mask, n_iter=5, mode=0, seed=0, n_lanes=4, bgd=None, fgd=None, post=None):
         """grabcut() on n_lanes contiguous sub-batches at once; same results (image b keeps seed + b).
 
         Sub-batch 0 runs on the caller's stream, the others on n_lanes - 1 streams of the engine.  HIP maps streams onto 4
@@ -69,8 +69,13 @@ class Engine:
         from concurrent.futures import ThreadPoolExecutor
         b = image.size(0)
         n_lanes = max(1, min(int(n_lanes), b))
+        # post(engine, lo, hi, binary[lo:hi]): per-image follow-up work (clean-up, composition) that a lane runs on its own
+        # stream as soon as ITS sub-batch is cut, under the other lanes' tails, instead of after the slowest lane
         if n_lanes == 1:
-            return self.grabcut(image, mask, n_iter, mode, None, seed, bgd, fgd)
+            out = self.grabcut(image, mask, n_iter, mode, None, seed, bgd, fgd)
+            if post is not None:
+                post(self, 0, b, out[0])
+            return out
         bounds = [b * i // n_lanes for i in range(n_lanes + 1)]
         if bgd is None:
             bgd = torch.zeros(b, 65, dtype=torch.float64, device=self.device)
@@ -88,6 +93,8 @@ class Engine:
             with torch.cuda.stream(stream):
                 out = eng.grabcut(image[lo:hi], mask[lo:hi], n_iter, mode, None, seed + lo, bgd[lo:hi], fgd[lo:hi])
                 binary[lo:hi].copy_(out[0])
+                if post is not None:
+                    post(eng, lo, hi, binary[lo:hi])
             stream.synchronize()
 
         if getattr(self, "_pool", None) is None or self._pool._max_workers < n_lanes - 1:
@@ -97,6 +104,8 @@ class Engine:
         futures = [self._pool.submit(run, i) for i in range(1, n_lanes)]
         out = self.grabcut(image[:bounds[1]], mask[:bounds[1]], n_iter, mode, None, seed, bgd[:bounds[1]], fgd[:bounds[1]])
         binary[:bounds[1]].copy_(out[0])
+        if post is not None:
+            post(self, 0, bounds[1], binary[:bounds[1]])
         for f in futures:
             f.result()
         return binary, mask, bgd, fgd

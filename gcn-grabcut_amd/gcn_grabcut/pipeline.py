@@ -282,18 +282,33 @@ class GCNGrabCutPipeline:
         mask = trimap.clone()
         lanes = want if b >= 8 * max(want, 1) else 1
         gc_img = bgr if cs == "rgb" else eng.convert_color8(bgr, cs)      # reference grabcut.py:73-79
-        binary, mask, bgd, fgd = eng.grabcut_lanes(gc_img, mask, self.gc_config.n_iter, 0, self.gc_config.seed, lanes)
+        # clean-up and composition are per image: without stage timing each GrabCut lane runs them for its own sub-batch as
+        # soon as it is cut (on its stream, under the other lanes' tails); with timing they stay a stage of their own
+        cleaned = eng.empty(*bgr.shape[:3], dtype=torch.uint8)
+        overlay = eng.empty(*bgr.shape[:3], 3, dtype=torch.uint8) if compose else None
+        rgba = eng.empty(*bgr.shape[:3], 4, dtype=torch.uint8) if compose else None
+
+        def post(leng, lo, hi, binary_part):
+            leng.clean_mask(binary_part, min_area_ratio, keep_largest, out=cleaned[lo:hi])
+            if compose:
+                leng.compose(bgr[lo:hi], cleaned[lo:hi], out=(overlay[lo:hi], rgba[lo:hi]))
+
+        fused_post = timing is None
+        binary, mask, bgd, fgd = eng.grabcut_lanes(gc_img, mask, self.gc_config.n_iter, 0, self.gc_config.seed, lanes,
+                                                   post=post if (fused_post and refine_iters <= 0) else None)
         if refine_iters > 0:
-            binary, mask, bgd, fgd = eng.grabcut_lanes(gc_img, mask, refine_iters, 2, self.gc_config.seed, lanes, bgd, fgd)
+            binary, mask, bgd, fgd = eng.grabcut_lanes(gc_img, mask, refine_iters, 2, self.gc_config.seed, lanes, bgd, fgd,
+                                                       post=post if fused_post else None)
         if timing is not None:
             timing["grabcut"] = tick() - t
 
         t = tick()
-        cleaned = eng.clean_mask(binary, min_area_ratio, keep_largest)
+        if not fused_post:
+            post(eng, 0, bgr.size(0), binary)
         out = {"binary_mask": cleaned, "trimap": trimap, "segments": seg, "graphs": graphs, "probs": probs,
                "gc_mask": mask}
         if compose:
-            out["overlay"], out["rgba"] = eng.compose(bgr, cleaned)
+            out["overlay"], out["rgba"] = overlay, rgba
         if timing is not None:
             timing["postprocess"] = tick() - t
         return out
