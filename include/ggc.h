@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define GGC_VERSION 100 /* 0.1.0 */
+#define GGC_VERSION 300 /* 0.3.0: round 3 — ggc_slic_rgb added, ggc_profile_enable(ctx, 2), one max-flow driver */
 
 enum {
     GGC_OK            =  0,
