@@ -630,13 +630,40 @@ __global__ void __launch_bounds__(1024) k_aggregate(int N, const float* __restri
 // falls back to global loads per block / per row.  Arithmetic and summation order are those of
 // k_aggregate.
 
+// Block shape of the 32-float slices (round 3, bench batch, us per launch of the gated kernel on one box): 512 threads with 8
+// neighbour rows per batch of LDS reads and the epilogue operands two rows ahead (116 VGPRs, 16 waves per CU) 60.3-62.0;
+// 256 threads 72-75 whatever the prefetch depth (2 / 4 / 6 rows): the kernel is short of WAVES, not of bytes in flight;
+// 768 threads, 2 rows per batch (76 VGPRs, 24 waves) 59.3-59.5; 1024 threads, 2 rows per batch, one row ahead (62 VGPRs, the
+// full 32 waves per CU) 57.6-58.0.  Anything that spills (768 / 1024 threads with 4 or 8 rows per batch) loses 15 us.
+#ifndef AGG_THREADS
+#define AGG_THREADS 1024
+#endif
+#ifndef AGG_PF
+#define AGG_PF 1
+#endif
+#ifndef AGG_UB
+#define AGG_UB 2
+#endif
+#ifndef AGG16_THREADS
+#define AGG16_THREADS 512
+#endif
+#ifndef AGG16_PF
+#define AGG16_PF 2
+#endif
+#ifndef AGG16_UB
+#define AGG16_UB 2
+#endif
 template <int SW> struct AggGraph {
-    static constexpr int LPR = SW / 4, RPW = 64 / LPR, RPP = 8 * RPW;          // 8 waves: rows per pass of the block
+    static constexpr int T = SW == 32 ? AGG_THREADS : AGG16_THREADS, NW = T / 64;   // threads per block
+    static constexpr int PF = SW == 32 ? AGG_PF : AGG16_PF;                // epilogue rows in flight ahead of the gather
+    static constexpr int UB = SW == 32 ? AGG_UB : AGG16_UB;                // neighbour rows per batch of LDS reads
+    static constexpr int LPR = SW / 4, RPW = 64 / LPR, RPP = NW * RPW;         // rows per pass of the block
     static constexpr int LDS = (SW == 32 ? 80 : 52) * 1024;                    // 2 (SW 32) or 3 (SW 16) blocks per CU
+    static constexpr int OCC = (SW == 32 ? 2 : 3) * T / 256 < 8 ? (SW == 32 ? 2 : 3) * T / 256 : 8;   // waves per SIMD the blocks of a CU need
     static constexpr int CAP_LDS = (LDS - SW * 4 - 4) / (SW * 4 + 4);          // tile row + dis entry, one zero row
     static constexpr int CAP = CAP_LDS < 1023 ? CAP_LDS : 1023;                // 10-bit row offsets in the packed columns
     static constexpr int K = (CAP + RPP - 1) / RPP;                            // passes for a full tile
-    static constexpr int FILL = (CAP * LPR + 511) / 512;                       // LDS-DMA pieces per thread
+    static constexpr int FILL = (CAP * LPR + T - 1) / T;                       // LDS-DMA pieces per thread
 };
 
 // broadcast lane U of every group of W lanes (W = 4 or 8): ds_swizzle, no address VGPR and no VALU
@@ -732,7 +759,7 @@ __device__ __forceinline__ void agg_row_generic(int row, int g0, int n_g, const 
 #define AGG_NT 7
 #endif
 template <int D, int MODE, int SW, bool GATED>
-__global__ void __launch_bounds__(512, 4) k_aggregate_graph(int G, const int32_t* __restrict__ node_ptr,
+__global__ void __launch_bounds__(AggGraph<SW>::T, AggGraph<SW>::OCC) k_aggregate_graph(int G, const int32_t* __restrict__ node_ptr,
                                                             const float* __restrict__ xw,
                                                             const int32_t* __restrict__ row_ptr,
                                                             const int32_t* __restrict__ col,
@@ -743,9 +770,9 @@ __global__ void __launch_bounds__(512, 4) k_aggregate_graph(int G, const int32_t
                                                             const float* __restrict__ h,
                                                             float* __restrict__ out) {
     using C = AggGraph<SW>;
-    constexpr int LPR = C::LPR, RPW = C::RPW, RPP = C::RPP, CAP = C::CAP, K = C::K, FILL = C::FILL, NS = D / SW, D4 = D / 4;
+    constexpr int LPR = C::LPR, RPW = C::RPW, RPP = C::RPP, CAP = C::CAP, K = C::K, FILL = C::FILL, NS = D / SW, D4 = D / 4, T = C::T;
     constexpr int NB = 2;                                  // column batches kept in registers (NB * LPR neighbours)
-    constexpr int PF = 2;                                  // epilogue rows kept in flight ahead of the gather (2 measured best; 4+ spills)
+    constexpr int PF = C::PF;                              // epilogue rows kept in flight ahead of the gather
     constexpr int ZROW = CAP;                              // all-zero tile row (and dis entry) the padding lanes point at
     static_assert(D % SW == 0, "slice width must divide D");
     static_assert(!GATED || MODE == 0, "the gated epilogue belongs to GCNConv");
@@ -782,18 +809,18 @@ __global__ void __launch_bounds__(512, 4) k_aggregate_graph(int G, const int32_t
     // tile + dis fill: LDS-DMA, no registers; a wave instruction writes 64 consecutive elements
 #pragma unroll
     for (int f = 0; f < FILL; ++f) {
-        const int i = tid + f * 512;
+        const int i = tid + f * T;
         if (i < n_g * LPR)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xw4g + (size_t)(g0 + i / LPR) * D4 + i % LPR),
-                                             (__attribute__((address_space(3))) void*)(tile + f * 512 + wave * 64), 16, 0, (AGG_NT & 4) ? 2 : 0);
+                                             (__attribute__((address_space(3))) void*)(tile + f * T + wave * 64), 16, 0, (AGG_NT & 4) ? 2 : 0);
     }
     if (MODE == 0) {
 #pragma unroll
-        for (int f = 0; f < (CAP + 511) / 512; ++f) {
-            const int i = tid + f * 512;
+        for (int f = 0; f < (CAP + T - 1) / T; ++f) {
+            const int i = tid + f * T;
             if (i < n_g)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dis + g0 + i),
-                                                 (__attribute__((address_space(3))) void*)(dis_l + f * 512 + wave * 64), 4, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dis_l + f * T + wave * 64), 4, 0, 0);
         }
     }
     if (tid < LPR) tile[ZROW * LPR + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -834,17 +861,20 @@ __global__ void __launch_bounds__(512, 4) k_aggregate_graph(int G, const int32_t
                 if (nb == 0 || nb * LPR < n) {
                     const int myoff = (cp[k] >> (10 * nb)) & 1023;
                     const float myw = (MODE == 0) ? dis_l[myoff] * di : 0.0f;
-                    v4f v[LPR];
-                    float wk[LPR];
-                    unroll_bcast<LPR, 0, LPR>([&](auto u) {
-                        v[u] = tile4[group_bcast<LPR, u>(myoff) * LPR + sl];
-                        if (MODE == 0) wk[u] = group_bcast<LPR, u>(myw);
-                    });
+                    constexpr int UB = C::UB < LPR ? C::UB : LPR;
+                    unroll_bcast<1, 0, LPR / UB>([&](auto ub) {
+                        v4f v[UB];
+                        float wk[UB];
+                        unroll_bcast<LPR, 0, UB>([&](auto u) {
+                            v[u] = tile4[group_bcast<LPR, ub * UB + u>(myoff) * LPR + sl];
+                            if (MODE == 0) wk[u] = group_bcast<LPR, ub * UB + u>(myw);
+                        });
 #pragma unroll
-                    for (int u = 0; u < LPR; ++u) {
-                        if (MODE == 0) acc += wk[u] * v[u];
-                        else acc += v[u];
-                    }
+                        for (int u = 0; u < UB; ++u) {
+                            if (MODE == 0) acc += wk[u] * v[u];
+                            else acc += v[u];
+                        }
+                    });
                 }
             }
             if (MODE == 0) {
@@ -1125,7 +1155,7 @@ static int launch_aggregate_graph_t(ggc_ctx* ctx, hipStream_t st, int G, const i
                                          hipFuncAttributeMaxDynamicSharedMemorySize, AggGraph<SW>::LDS));
         attr_set.done(ctx->device);
     }
-    hipLaunchKernelGGL((k_aggregate_graph<D, MODE, SW, GATED>), dim3(cdiv(G, 8) * 8 * (D / SW)), dim3(512), AggGraph<SW>::LDS, st,
+    hipLaunchKernelGGL((k_aggregate_graph<D, MODE, SW, GATED>), dim3(cdiv(G, 8) * 8 * (D / SW)), dim3(AggGraph<SW>::T), AggGraph<SW>::LDS, st,
                        G, node_ptr, xw, row_ptr, col, pack, dis, bias, gate, h, out);
     GGC_LAUNCH_CHECK(ctx);
     return GGC_OK;
@@ -1137,6 +1167,9 @@ static int launch_aggregate_graph_t(ggc_ctx* ctx, hipStream_t st, int G, const i
 static int agg_graph_slice(int N, int G) {
     if (G <= 0 || knobs().agg_direct) return 0;
     const double want = 1.02 * (double)N / G;
+#ifdef AGG_FORCE16
+    return want <= AggGraph<16>::CAP ? 16 : 0;
+#endif
     return want <= AggGraph<32>::CAP ? 32 : want <= AggGraph<16>::CAP ? 16 : 0;
 }
 
