@@ -161,9 +161,10 @@ def main() -> None:
     ap.add_argument("--workload", choices=["full", "gcn"], default="full")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent sub-batches of the GrabCut stage (full workload; "
                     "default 4 with one pipeline, 1 per pipeline otherwise)")
-    ap.add_argument("--overlap-pass", type=int, default=0, help="after the contract's run (N=1, full workload, one pipeline): a second "
-                    "timed pass of the same steps over this many overlapping pipelines, reported as 'overlapped' (0 = skip, the "
-                    "default: the pass re-runs every kernel under contention, which would blur a rocprofv3 summary of the command)")
+    ap.add_argument("--overlap-pass", type=int, default=-1, help="after the contract's run (N=1, full workload, one pipeline): a second "
+                    "timed pass of the same steps over this many overlapping pipelines, reported as 'overlapped' (informational, "
+                    "never `value`).  0 = skip; -1 (default) = 3, except under rocprofv3, where the pass is skipped: it re-runs "
+                    "every kernel under contention, which would blur the profiler's per-kernel summary of the command")
     ap.add_argument("--pipelines", type=int, default=1, help="full workload: pipelines (private contexts, own HIP streams and "
                     "host threads) that take the timed steps in turn, so consecutive batches overlap")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default 256 full / 64 gcn)")
@@ -177,6 +178,9 @@ def main() -> None:
                     "all-reduce of the step time and the gather of the per-rank records even when WORLD_SIZE is 1 (warms the "
                     "N > 1 path on a one-GPU box; under torch.distributed.run --nproc-per-node 1 or on its own)")
     args = ap.parse_args()
+    if args.overlap_pass < 0:
+        profiled = any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH", "ROCPROFILER_LIBRARY_CTOR"))
+        args.overlap_pass = 0 if profiled else 3
     batch_size = args.batch or (256 if args.workload == "full" else 64)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_own_ranks(args.gpus)

@@ -24,7 +24,7 @@ def test_single_rank_job_runs_the_collectives(gpu_ctx):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "16",
-           "--cpu-sample", "0", "--h2d-steps", "0", "--force-collective"]
+           "--cpu-sample", "0", "--h2d-steps", "0", "--overlap-pass", "0", "--force-collective"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
