@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(1024) k_aggregate(int N, const float* __restri
 // it copies its [n_g, SW] slice of xw (and the graph's dis) into LDS once by LDS-DMA (128-B segments,
 // every byte of xw is read from memory exactly once) and then serves every neighbour row and the
 // self loop by ds_read_b128 on the 256 B/clk LDS pipe.  Two blocks share a CU (80 KiB each), so one
-// block's fill overlaps the other's gather (three 52-KiB blocks with 16-float slices for larger graphs).  The D/SW slices of one graph run on the same XCD and
+// block's fill overlaps the other's gather.  The D/SW slices of one graph run on the same XCD and
 // share the CSR through its L2.  A graph with more than CAP nodes, or an edge that leaves its graph,
 // falls back to global loads per block / per row.  Arithmetic and summation order are those of
 // k_aggregate.
@@ -644,22 +644,16 @@ __global__ void __launch_bounds__(1024) k_aggregate(int N, const float* __restri
 #ifndef AGG_UB
 #define AGG_UB 2
 #endif
-#ifndef AGG16_THREADS
-#define AGG16_THREADS 512
-#endif
-#ifndef AGG16_PF
-#define AGG16_PF 2
-#endif
-#ifndef AGG16_UB
-#define AGG16_UB 2
-#endif
+// (16-float slices — 64-byte fill segments, three 52-KB blocks per CU, meant for graphs of 620-782 nodes — took 143-150 us on
+// the same batch against 96 us for the direct gather k_aggregate: that route is gone, such batches gather directly.)
 template <int SW> struct AggGraph {
-    static constexpr int T = SW == 32 ? AGG_THREADS : AGG16_THREADS, NW = T / 64;   // threads per block
-    static constexpr int PF = SW == 32 ? AGG_PF : AGG16_PF;                // epilogue rows in flight ahead of the gather
-    static constexpr int UB = SW == 32 ? AGG_UB : AGG16_UB;                // neighbour rows per batch of LDS reads
+    static_assert(SW == 32, "one slice width is built");
+    static constexpr int T = AGG_THREADS, NW = T / 64;                         // threads per block
+    static constexpr int PF = AGG_PF;                                          // epilogue rows in flight ahead of the gather
+    static constexpr int UB = AGG_UB;                                          // neighbour rows per batch of LDS reads
     static constexpr int LPR = SW / 4, RPW = 64 / LPR, RPP = NW * RPW;         // rows per pass of the block
-    static constexpr int LDS = (SW == 32 ? 80 : 52) * 1024;                    // 2 (SW 32) or 3 (SW 16) blocks per CU
-    static constexpr int OCC = (SW == 32 ? 2 : 3) * T / 256 < 8 ? (SW == 32 ? 2 : 3) * T / 256 : 8;   // waves per SIMD the blocks of a CU need
+    static constexpr int LDS = 80 * 1024;                                      // 2 blocks per CU
+    static constexpr int OCC = 2 * T / 256 < 8 ? 2 * T / 256 : 8;              // waves per SIMD the blocks of a CU need
     static constexpr int CAP_LDS = (LDS - SW * 4 - 4) / (SW * 4 + 4);          // tile row + dis entry, one zero row
     static constexpr int CAP = CAP_LDS < 1023 ? CAP_LDS : 1023;                // 10-bit row offsets in the packed columns
     static constexpr int K = (CAP + RPP - 1) / RPP;                            // passes for a full tile
@@ -1161,16 +1155,13 @@ static int launch_aggregate_graph_t(ggc_ctx* ctx, hipStream_t st, int G, const i
     return GGC_OK;
 }
 
-// Column-slice width of the graph-resident gather for G graphs with N nodes in total: the widest slice whose
-// [nodes-per-graph, SW] tile fits half a CU's LDS with a little head-room over the mean graph size (a larger
-// graph falls back per block); 0 = use the direct gather.
+// Column-slice width of the graph-resident gather for G graphs with N nodes in total: 32 when the [nodes-per-graph, 32]
+// tile fits half a CU's LDS with a little head-room over the mean graph size (a larger graph falls back per block);
+// 0 = use the direct gather.
 static int agg_graph_slice(int N, int G) {
     if (G <= 0 || knobs().agg_direct) return 0;
     const double want = 1.02 * (double)N / G;
-#ifdef AGG_FORCE16
-    return want <= AggGraph<16>::CAP ? 16 : 0;
-#endif
-    return want <= AggGraph<32>::CAP ? 32 : want <= AggGraph<16>::CAP ? 16 : 0;
+    return want <= AggGraph<32>::CAP ? 32 : 0;
 }
 
 // The forward pass hands over the batch structure (G graphs, node_ptr) and the packed column words built by
@@ -1185,8 +1176,7 @@ static int build_agg_pack(ggc_ctx* ctx, hipStream_t st, int N, int G, const int3
     const int lpr = sw / 4;
     int32_t* pack = scratch_t<int32_t>(ctx, S_AGG_PACK, (size_t)N * lpr);
     if (!pack) return GGC_E_OOM;
-    if (sw == 32) hipLaunchKernelGGL(k_agg_pack<32>, dim3(cdiv(N * lpr, 256)), dim3(256), 0, st, N, node_ptr, batch, row_ptr, col, pack);
-    else          hipLaunchKernelGGL(k_agg_pack<16>, dim3(cdiv(N * lpr, 256)), dim3(256), 0, st, N, node_ptr, batch, row_ptr, col, pack);
+    hipLaunchKernelGGL(k_agg_pack<32>, dim3(cdiv(N * lpr, 256)), dim3(256), 0, st, N, node_ptr, batch, row_ptr, col, pack);
     GGC_LAUNCH_CHECK(ctx);
     ag.G = G; ag.sw = sw; ag.node_ptr = node_ptr; ag.pack = pack;
     return GGC_OK;
@@ -1209,7 +1199,6 @@ static int launch_aggregate(ggc_ctx* ctx, hipStream_t st, int N, const float* xw
                             const float* h, float* out, const AggGraphs& ag = AggGraphs{}) {
     ProfScope prof(ctx, st, MODE == 0 ? "gcn_aggregate" : "sage_aggregate");
     if (ag.sw == 32) return launch_aggregate_graph<D, MODE, 32>(ctx, st, ag, xw, row_ptr, col, dis, bias, gate, h, out);
-    if (ag.sw == 16) return launch_aggregate_graph<D, MODE, 16>(ctx, st, ag, xw, row_ptr, col, dis, bias, gate, h, out);
     constexpr int threads = 256;
     const int rows_per_block = AggCfg<D>::RPW * (threads / 64);
     hipLaunchKernelGGL((k_aggregate<D, MODE>), dim3(cdiv(N, rows_per_block)), dim3(threads), 0, st,

@@ -124,18 +124,18 @@ def _hub_graph(n, hub_deg, seed):
     return x, np.stack([src, dst]).astype(np.int64), np.concatenate([ea, ea2], 0)
 
 
-@pytest.mark.parametrize("case", ["graph_over_tile", "slice16", "direct", "hub_rows", "edges_leave_graph"])
+@pytest.mark.parametrize("case", ["graph_over_tile", "mean_over_tile", "direct", "hub_rows", "edges_leave_graph"])
 def test_forward_aggregation_routes(oracle, gpu_ctx, case):
     """The forward pass aggregates with the graph-resident LDS kernel; every route around it must give the same
     logits: a graph larger than the 619-row tile inside a batch of small ones (per-block fallback), a mean size
-    that selects 16-float slices, one that selects the direct gather, rows with more than 16 neighbours, and a
+    just above the tile (the direct gather since the 16-float slices went), one far above it, rows with more than 16 neighbours, and a
     batch vector that cuts through edges (neighbours outside the block's graph)."""
     from gcn_grabcut.data import Batch
     model, sd = seeded_state_dict(128, 2, seed=3)
     model = model.to("cuda").eval()
     if case == "graph_over_tile":
         graphs = [superpixel_like_graph(n=n, seed=n) for n in (700, 420, 380)]
-    elif case == "slice16":
+    elif case == "mean_over_tile":
         graphs = [superpixel_like_graph(n=n, seed=n) for n in (760, 700)]
     elif case == "direct":
         graphs = [superpixel_like_graph(n=1203, seed=5)]
