@@ -3,7 +3,8 @@ GCNGrabCutPipeline.segment_batch_device against the CPU oracle (label map, trima
 Environment: FUZZ_N cases (40), FUZZ_SEED (1), FUZZ_MIN / FUZZ_MAX image side (20 / 260), FUZZ_PX_PER_SEG (30), FUZZ_OPTIONS=1 also draws
 the SuperpixelGraphConfig / segment() options (use_lab, connectivity, n_nonlocal, compactness, sigma, thresholds, refine_iters, ...).
     gpurun -- 'FUZZ_OPTIONS=1 FUZZ_N=120 python3 tests/fuzz_parity.py'
-Round 3: 60 + 150 (sides 6-70) + 25 (sides 250-640) + 120 (with options) cases, no mismatch."""
+FUZZ_KIND=grabcut fuzzes the GrabCut class instead (trimap / rectangle starts, refine, colour spaces, 1-5 iterations).
+Round 3: 60 + 150 (sides 6-70) + 25 (sides 250-640) + 120 (with options) pipeline cases and 150 GrabCut-class cases, no mismatch."""
 import os, sys, time
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "src")); sys.path.insert(0, os.path.join(R, "tests"))
@@ -14,6 +15,54 @@ from gcn_grabcut.synthetic import synthetic_batch
 from oracle import oracle as orc          # checker
 
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
+
+
+def fuzz_grabcut_class():
+    """FUZZ_KIND=grabcut: the GrabCut class (run_with_trimap / run_with_bbox, then refine) against oracle.grabcut, incl. one-sided
+    and empty trimaps, rectangles that touch or leave the image, 1-5 iterations, the three colour spaces."""
+    from gcn_grabcut.grabcut import GrabCut, GrabCutConfig
+    from gcn_grabcut.synthetic import synthetic_image
+    bad = 0
+    for case in range(int(os.environ.get("FUZZ_N", "40"))):
+        h, w = int(rng.integers(8, 200)), int(rng.integers(8, 200))
+        img = synthetic_image(h, w, int(rng.integers(0, 1000))) if rng.random() < 0.6 else rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        n_iter, cs, seed = int(rng.integers(1, 6)), str(rng.choice(["rgb", "rgb", "hsv", "lab"])), int(rng.integers(0, 100))
+        gc = GrabCut(img, GrabCutConfig(n_iter=n_iter, color_space=cs, seed=seed))
+        conv = img if cs == "rgb" else orc.convert_color8(img, cs)
+        desc = f"grabcut case {case}: {h}x{w} it={n_iter} {cs} seed={seed}"
+        if rng.random() < 0.5:
+            x0, y0 = int(rng.integers(-3, w - 1)), int(rng.integers(-3, h - 1))
+            rect = (x0, y0, int(rng.integers(1, w + 4)), int(rng.integers(1, h + 4)))
+            desc += f" rect={rect}"
+            try:
+                got = gc.run_with_bbox(rect)
+            except Exception as e:
+                print(desc, "raised", f"{type(e).__name__}: {e}"[:200]); continue
+            wb, wm, bgd, fgd, rc = orc.grabcut(conv, None, n_iter=n_iter, mode=1, rect=rect, seed=seed)
+        else:
+            tri = np.full((h, w), int(rng.choice([2, 3])), np.uint8)
+            for _ in range(int(rng.integers(0, 5))):                          # a few rectangles of random labels (0..3), maybe none
+                ya, xa = int(rng.integers(0, h)), int(rng.integers(0, w))
+                tri[ya:ya + int(rng.integers(1, h)), xa:xa + int(rng.integers(1, w))] = int(rng.integers(0, 4))
+            desc += f" trimap labels={np.unique(tri).tolist()}"
+            got = gc.run_with_trimap(tri)
+            wb, wm, bgd, fgd, rc = orc.grabcut(conv, tri, n_iter, 0, None, seed)
+        ok = np.array_equal(got, wb) and np.array_equal(gc.mask, wm)
+        if ok and rc == 0 and rng.random() < 0.5:
+            k = int(rng.integers(1, 4))
+            got2 = gc.refine(k)
+            wb2, wm2, *_ = orc.grabcut(conv, wm, k, 2, None, seed, bgd, fgd)
+            ok = np.array_equal(got2, wb2) and np.array_equal(gc.mask, wm2)
+            desc += f" refine={k}"
+        if not ok: print(desc, "MISMATCH"); bad += 1
+        elif case % 10 == 0: print(desc, "ok", flush=True)
+    print("FUZZ DONE: mismatching cases", bad)
+
+
+if os.environ.get("FUZZ_KIND", "pipeline") == "grabcut":
+    fuzz_grabcut_class()
+    sys.exit(0)
+
 model, sd = seeded_state_dict(32, 2, seed=5)
 st = {k: v.numpy() for k, v in sd.items() if v.dtype.is_floating_point}
 bad = 0

@@ -19,3 +19,10 @@ def test_fuzzed_cases_match_the_oracle(options, seed, lo, hi):
     assert r.returncode == 0, r.stderr[-3000:]
     assert "FUZZ DONE: mismatching cases 0" in r.stdout, r.stdout[-3000:]
     assert "RAISED" not in r.stdout, r.stdout[-3000:]
+
+
+def test_fuzzed_grabcut_class_matches_the_oracle():
+    env = dict(os.environ, FUZZ_KIND="grabcut", FUZZ_N="40", FUZZ_SEED="23", GRAFT_REPO_ROOT=str(ROOT))
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_parity.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "FUZZ DONE: mismatching cases 0" in r.stdout, r.stdout[-3000:]
