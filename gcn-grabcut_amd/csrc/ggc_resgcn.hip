@@ -372,14 +372,24 @@ struct GemmArgs {
     int Dt = 0;                      // true width for the LayerNorm statistics (0: D), see k_input
 };
 
+#ifdef GEMM_TRACE     // experiment build: per-wave phase stamps of k_gemm<128, 0> kept in SGPRs (no scheduling fences)
+__device__ unsigned long long g_gemm_trace[8192 * 8];
+#define GEMM_STAMP(i) do { if (D == 128 && MODE == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i]) :: "memory"); } while (0)
+#else
+#define GEMM_STAMP(i) do {} while (0)
+#endif
 template <int D, int MODE>
 __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
+#ifdef GEMM_TRACE
+    unsigned long long stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     constexpr int T = D / 32, KH = D / 2;
     extern __shared__ float4 smem4[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hk = lane >> 5, li = lane & 31;
     const int r0 = (blockIdx.x * 4 + wave) * 32;
     const int row = min(r0 + li, N - 1);
+    GEMM_STAMP(0);
 
     f32x16 acc[T];
 #pragma unroll
@@ -393,8 +403,15 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
         const float* Wp = ph ? g.Wp2 : g.Wp1;
         const float* A = ph ? g.A2 : g.A1;
         if (ph) __syncthreads();
-        for (int i = tid; i < D * D / 4; i += 256) smem4[i] = reinterpret_cast<const float4*>(Wp)[i];
+        {   // all D * D / 1024 loads of a thread in flight at once (rolled, the loop paid one memory round trip per 4 KB: 17 k cycles at D = 128)
+            float4 wv[D * D / 1024];
+#pragma unroll
+            for (int q = 0; q < D * D / 1024; ++q) wv[q] = reinterpret_cast<const float4*>(Wp)[tid + q * 256];
+#pragma unroll
+            for (int q = 0; q < D * D / 1024; ++q) smem4[tid + q * 256] = wv[q];
+        }
         __syncthreads();
+        GEMM_STAMP(1);
 
         float a[KH];
         const float4* ap = reinterpret_cast<const float4*>(A + (size_t)row * D + hk * KH);
@@ -413,6 +430,10 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
 #pragma unroll
             for (int s = 0; s < KH; ++s) s1 += a[s];
             s1 += __shfl_xor(s1, 32, 64);
+#ifdef GEMM_TRACE
+            if (D == 128 && MODE == 0) asm volatile("s_nop 0" :: "v"(s1));       // the stamp below waits for the row sum, i.e. for the loads
+#endif
+            GEMM_STAMP(2);
             const int dt = g.Dt > 0 ? g.Dt : D, nv = min(max(dt - hk * KH, 0), KH);   // this lane's channels below the true width
             const float mean = s1 / (float)dt;
             float s2 = 0.0f;
@@ -425,19 +446,34 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
 #pragma unroll
             for (int s = 0; s < KH; ++s) a[s] = (a[s] - mean) * rstd * lw[s] + lb[s];
         }
+#ifdef GEMM_TRACE
+        if (D == 128 && MODE == 0) asm volatile("s_nop 0" :: "v"(a[0]), "v"(a[KH - 1]));
+#endif
+        GEMM_STAMP(3);
+        // Consecutive MFMAs go to DIFFERENT accumulators (the T column tiles of one k step): an MFMA that depends on the one
+        // before it waits at the head of the SIMD's vector issue port until that one retires, and nothing of the SIMD's
+        // other wave issues meanwhile (phase stamps: with the four k steps of a B fragment back to back on one accumulator
+        // the two waves of a SIMD never overlapped at all).  Each accumulator still sees its k steps in the same order.
 #pragma unroll
         for (int s4 = 0; s4 < KH / 4; ++s4) {
+            float bq[T][4];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const float4 b = smem4[(s4 * T + t) * 64 + lane];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 0], b.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 1], b.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 2], b.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 3], b.w, acc[t], 0, 0, 0);
+                bq[t][0] = b.x; bq[t][1] = b.y; bq[t][2] = b.z; bq[t][3] = b.w;
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + j], bq[t][j], acc[t], 0, 0, 0);
         }
     }
 
+#ifdef GEMM_TRACE
+    if (D == 128 && MODE == 0) asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[T - 1][15]));
+#endif
+    GEMM_STAMP(4);
     // C/D layout: col = 32 t + (lane & 31), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     if (MODE == 3) {                 // plain product (GCNTrimapNet: no prologue norm), optionally accumulated
 #pragma unroll
@@ -521,6 +557,17 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
             }
         }
     }
+#ifdef GEMM_TRACE
+    GEMM_STAMP(5);
+    __builtin_amdgcn_s_waitcnt(0);
+    GEMM_STAMP(6);
+    if (D == 128 && MODE == 0 && lane == 0 && blockIdx.x * 4 + wave < 8192) {
+        unsigned long long* o = g_gemm_trace + (blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = stamp[i];
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+    }
+#endif
 }
 
 // ------------------------------------------------- M3/M4: CSR scatter-gather
@@ -1136,6 +1183,20 @@ static int launch_gemm(ggc_ctx* ctx, hipStream_t st, int N, const GemmArgs& a) {
     ProfScope prof(ctx, st, MODE == 0 ? "gcn_gemm" : MODE == 1 ? "sage_gemm" : (MODE == 2 || MODE == 4) ? "head_gemm" : "plain_gemm");
     hipLaunchKernelGGL((k_gemm<D, MODE>), dim3(cdiv(N, 128)), dim3(256), lds, st, N, a);
     GGC_LAUNCH_CHECK(ctx);
+#ifdef GEMM_TRACE
+    if (D == 128 && MODE == 0 && std::getenv("GGC_GEMM_TRACE")) {
+        static std::vector<unsigned long long> host(8192 * 8);
+        int occ = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&k_gemm<D, MODE>), 256, lds);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_gemm_trace), host.size() * 8);
+        if (FILE* f = std::fopen(std::getenv("GGC_GEMM_TRACE"), "ab")) {
+            const long long n = std::min(cdiv(N, 128) * 4, 8192);
+            std::fwrite(&n, 8, 1, f); std::fwrite(host.data(), 8, (size_t)n * 8, f); std::fclose(f);
+        }
+        std::fprintf(stderr, "k_gemm<128,0> trace: blocks per CU %d\n", occ);
+    }
+#endif
     return GGC_OK;
 }
 
