@@ -402,6 +402,13 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
     for (int ph = 0; ph < PHASES; ++ph) {
         const float* Wp = ph ? g.Wp2 : g.Wp1;
         const float* A = ph ? g.A2 : g.A1;
+        // the wave's rows are requested first: their latency runs under the staging of W
+        float4 av[KH / 4];
+        {
+            const float4* ap = reinterpret_cast<const float4*>(A + (size_t)row * D + hk * KH);
+#pragma unroll
+            for (int q = 0; q < KH / 4; ++q) av[q] = ap[q];
+        }
         if (ph) __syncthreads();
         {   // all D * D / 1024 loads of a thread in flight at once (rolled, the loop paid one memory round trip per 4 KB: 17 k cycles at D = 128)
             float4 wv[D * D / 1024];
@@ -414,10 +421,9 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
         GEMM_STAMP(1);
 
         float a[KH];
-        const float4* ap = reinterpret_cast<const float4*>(A + (size_t)row * D + hk * KH);
 #pragma unroll
         for (int q = 0; q < KH / 4; ++q) {
-            const float4 v = ap[q];
+            const float4 v = av[q];
             a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
         }
         if (MODE == 2 || MODE == 4) {
@@ -450,10 +456,10 @@ __global__ void __launch_bounds__(256) k_gemm(int N, GemmArgs g) {
         if (D == 128 && MODE == 0) asm volatile("s_nop 0" :: "v"(a[0]), "v"(a[KH - 1]));
 #endif
         GEMM_STAMP(3);
-        // Consecutive MFMAs go to DIFFERENT accumulators (the T column tiles of one k step): an MFMA that depends on the one
-        // before it waits at the head of the SIMD's vector issue port until that one retires, and nothing of the SIMD's
-        // other wave issues meanwhile (phase stamps: with the four k steps of a B fragment back to back on one accumulator
-        // the two waves of a SIMD never overlapped at all).  Each accumulator still sees its k steps in the same order.
+        // Consecutive MFMAs go to different accumulators (the T column tiles of one k step); each accumulator still sees its
+        // k steps in the same order.  (Phase stamps, GEMM_TRACE: the MFMA loops of the two waves of a SIMD never overlap, in this
+        // order or with the four k steps of a B fragment back to back on one accumulator, and the other wave's LayerNorm
+        // crawls meanwhile — the f32 MFMA runs at the vector rate and leaves the SIMD's vector issue little room.)
 #pragma unroll
         for (int s4 = 0; s4 < KH / 4; ++s4) {
             float bq[T][4];
