@@ -352,12 +352,16 @@ __global__ void __launch_bounds__(256) k_slic_update(SlicGeom g, const float* __
                 if (hit) { const float* px = im + ((size_t)y * g.W + x) * 3; v0 = px[0]; v1 = px[1]; v2 = px[2]; isx += x; }
                 const int n = __popc(m);
                 cnt += n; isy += n * y;
-                while (__any(m != 0u)) {
-                    const int src = sub * UPD_LANES + (m ? __ffs((int)m) - 1 : 0);
-                    const float t0 = __shfl(v0, src, 64), t1 = __shfl(v1, src, 64), t2 = __shfl(v2, src, 64);
-                    if (m) { s0 += t0; s1 += t1; s2 += t2; }
-                    m &= m - 1u;
-                }
+                // the chunk's 8 pixels in x order, every lane of the group keeping the same running sums: lane u's value is
+                // broadcast by ds_swizzle (no address register) and added unconditionally — a lane without a hit holds +0,
+                // and s + (+0) == s bit for bit (s never is -0: it starts at +0).  The loop over the set bits this replaces
+                // spent 14 instructions per member pixel on find-first-set, three ds_bpermute and the loop test.
+                static_assert(UPD_LANES == 8, "the broadcast pattern is written for groups of 8 lanes");
+#define GGC_UPD_STEP(U) { s0 += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v0), 0x18 | ((U) << 5))); \
+                          s1 += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v1), 0x18 | ((U) << 5))); \
+                          s2 += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v2), 0x18 | ((U) << 5))); }
+                GGC_UPD_STEP(0) GGC_UPD_STEP(1) GGC_UPD_STEP(2) GGC_UPD_STEP(3) GGC_UPD_STEP(4) GGC_UPD_STEP(5) GGC_UPD_STEP(6) GGC_UPD_STEP(7)
+#undef GGC_UPD_STEP
             }
         }
 #pragma unroll
