@@ -323,13 +323,16 @@ __global__ void __launch_bounds__(256) k_slic_update(SlicGeom g, const float* __
         rows_max = max(rows_max, __shfl_xor(rows_max, off, 64));
         chunks_max = max(chunks_max, __shfl_xor(chunks_max, off, 64));
     }
-    // labels of (row ry, chunks c0 .. c0 + UPD_CH - 1); -1 outside the group's window
+    // labels of (row ry, chunks c0 .. c0 + UPD_CH - 1); -1 outside the group's window.  One pointer per lane and row, the
+    // chunks at constant offsets from it, the lane's number of chunks inside the window counted once (the kernel is bound by
+    // instruction issue: the per-chunk 64-bit index arithmetic was a third of the row's instructions)
+    const int32_t* lane_p = lb + (size_t)bd.x * g.W + bd.z + sl;
+    const int nvc = (bd.w - bd.z - sl + UPD_LANES - 1) / UPD_LANES;           // chunks c with bd.z + c * UPD_LANES + sl < bd.w
     auto load_row = [&](int ry, int c0, int (&lab)[UPD_CH]) {
+        const int32_t* rp = lane_p + (size_t)ry * g.W + c0 * UPD_LANES;
+        const int nv = ry < rows ? nvc - c0 : 0;
 #pragma unroll
-        for (int c = 0; c < UPD_CH; ++c) {
-            const int x = bd.z + (c0 + c) * UPD_LANES + sl;
-            lab[c] = (ry < rows && x < bd.w) ? lb[(size_t)(bd.x + ry) * g.W + x] : -1;
-        }
+        for (int c = 0; c < UPD_CH; ++c) lab[c] = c < nv ? rp[c * UPD_LANES] : -1;
     };
     // blocks of UPD_CH chunks in raster order: (row 0, block 0), (row 0, block 1), ..., (row 1, block 0), ...
     const int nblk = (chunks_max + UPD_CH - 1) / UPD_CH, total = rows_max * nblk;
