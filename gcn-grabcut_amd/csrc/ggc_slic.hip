@@ -202,7 +202,7 @@ __global__ void k_init_centers(SlicGeom g, float* __restrict__ centers, int4* __
 
 struct Cand { int k, y0, y1, x0, x1; float cy, cx, c0, c1, c2; };
 
-constexpr int TILE_W = 32, TILE_H = 16;     // two pixels per thread: (x, y) and (x, y + 8)
+constexpr int TILE_W = 32, TILE_H = 16;     // two pixels per thread: (x, y) and (x, y + 4) inside the wave's 16 x 8 quarter
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -222,10 +222,13 @@ __global__ void __launch_bounds__(256) k_slic_assign(SlicGeom g, const float* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
     const int tx0 = blockIdx.x * TILE_W, ty0 = blockIdx.y * TILE_H;
-    const int px = tx0 + (tid & 31), pya = ty0 + (tid >> 5), pyb = pya + 8;
+    // a wave owns a compact 16 x 8 quarter of the tile (two pixels per lane, four rows apart): a candidate whose window misses
+    // the quarter is skipped by the whole wave (the exec-zero branch below) — 24 of the tile's ~33 candidates reach a quarter,
+    // where every wave used to walk all of them for its two full-width row pairs
+    const int px = tx0 + (wave & 1) * 16 + (lane & 15), pya = ty0 + (wave >> 1) * 8 + (lane >> 4), pyb = pya + 4;
     const bool ina = px < g.W && pya < g.H, inb = px < g.W && pyb < g.H;
     const size_t P = (size_t)g.H * g.W;
-    const size_t pa = (size_t)b * P + (size_t)pya * g.W + px, pb = pa + (size_t)8 * g.W;
+    const size_t pa = (size_t)b * P + (size_t)pya * g.W + px, pb = pa + (size_t)4 * g.W;
     v2f i0 = 0.f, i1 = 0.f, i2 = 0.f;
     if (ina) { i0.x = image[3 * pa]; i1.x = image[3 * pa + 1]; i2.x = image[3 * pa + 2]; }
     if (inb) { i0.y = image[3 * pb]; i1.y = image[3 * pb + 1]; i2.y = image[3 * pb + 2]; }
